@@ -1,0 +1,80 @@
+// Shared plumbing of the C-ABI translation units: error reporting, dtype
+// dispatch, the handle layout. Nothing here is visible through include/accblas.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/accblas.h"
+#include "dot_kernels.hpp"
+
+
+struct accblas_handle {
+    int device;
+    int num_cus;
+    accblas_dot_mode dot_mode;
+    // one device allocation: [partials | ticket(16 B) | scalar(16 B) |
+    // trsv helper(16 B)]
+    void *workspace;
+    accblas::dev::dot_workspace dot_ws;
+    std::uint32_t *trsv_helper;
+};
+
+
+namespace accblas {
+
+
+/** Records `message` as the calling thread's last error and returns `code`. */
+int set_error(int code, const std::string &message);
+
+/** hipError_t -> status; records file-free message "what: hipGetErrorString". */
+int check_hip(hipError_t err, const char *what);
+
+
+template <typename T>
+struct type_tag {
+    using type = T;
+};
+
+using f16 = _Float16;
+
+
+/** Calls f(type_tag<T>) for the element type named by `t`. */
+template <typename F>
+int dispatch_type(accblas_dtype t, F &&f)
+{
+    switch (t) {
+    case ACCBLAS_F16:
+        return f(type_tag<f16>{});
+    case ACCBLAS_F32:
+        return f(type_tag<float>{});
+    case ACCBLAS_F64:
+        return f(type_tag<double>{});
+    }
+    return set_error(ACCBLAS_ERR_INVALID_ARGUMENT, "unknown accblas_dtype");
+}
+
+/** Arithmetic types are fp32 and fp64 only. */
+template <typename F>
+int dispatch_arithmetic(accblas_dtype t, F &&f)
+{
+    switch (t) {
+    case ACCBLAS_F32:
+        return f(type_tag<float>{});
+    case ACCBLAS_F64:
+        return f(type_tag<double>{});
+    default:
+        return set_error(ACCBLAS_ERR_UNSUPPORTED_TYPES,
+                         "arithmetic type must be f32 or f64");
+    }
+}
+
+inline hipStream_t as_stream(void *stream)
+{
+    return static_cast<hipStream_t>(stream);
+}
+
+
+}  // namespace accblas

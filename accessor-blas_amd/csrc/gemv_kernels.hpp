@@ -1,0 +1,309 @@
+// GEMV kernels for gfx950: res = alpha * A * x + beta * res, A row-major.
+//
+// Replaces `kernel::gemv` / `kernel::acc_gemv` and their launchers
+// (`/root/reference/cuda/gemv_kernels.cuh:30-64,79-113,136-193`). The maths
+// and the accessor contract are the reference's; the shape is not. The
+// reference runs one 512-thread block per row with 4/8-byte scalar loads and
+// a 4-barrier shared-memory tree. Here (MI355X, HBM-bound):
+//   * a group of WPR waves owns R consecutive rows and sweeps them together;
+//     every lane issues 16-byte loads of the STORAGE type (8 x fp16 /
+//     4 x fp32 / 2 x fp64), so 8 lanes cover one 128 B line and one wave
+//     instruction moves 1 KiB; R * UNROLL independent row loads per lane are
+//     in flight before the first FMA;
+//   * the x chunk a lane loads is widened once and reused for the R rows;
+//   * values are widened to the arithmetic type in registers, FMA'd, reduced
+//     with a 6-step 64-lane shuffle; waves of a group combine through LDS
+//     (one value per wave and row), no barrier tree;
+//   * anything the vector path cannot take (unaligned base or row stride,
+//     incx != 1) goes through `gemv_generic`, which uses only `operator()`.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "views.hpp"
+#include "wave_primitives.hpp"
+
+
+namespace accblas {
+namespace dev {
+
+
+/** Tuning knobs of the vector kernel. */
+template <int Waves, int WavesPerRowGroup, int RowsPerGroup, int Unroll,
+          bool NonTemporal>
+struct gemv_config {
+    static constexpr int waves = Waves;          // waves per workgroup
+    static constexpr int wpr = WavesPerRowGroup; // waves sharing a row group
+    static constexpr int rows = RowsPerGroup;    // rows swept together
+    static constexpr int unroll = Unroll;        // 16-byte loads per row/iter
+    static constexpr bool nt = NonTemporal;
+    static constexpr int groups = Waves / WavesPerRowGroup;
+    static constexpr int rows_per_block = groups * RowsPerGroup;
+    static_assert(Waves % WavesPerRowGroup == 0, "waves must split evenly");
+};
+
+
+namespace kernel {
+
+
+/**
+ * Vector-load GEMV. Requirements checked by the launcher: storage pointer of
+ * mtx and x aligned to Vec*sizeof(St), row stride % Vec == 0, x increment 1.
+ * res may have any increment (it is only touched through operator()).
+ *
+ * Follows `cuda/gemv_kernels.cuh:79-113` in meaning: local_result +=
+ * mtx(row, col) * x(col, 0) in ArType, then
+ * res(row,0) = alpha*sum (+ beta*res(row,0) if beta != 0).
+ */
+template <typename Config, int Vec, typename ArType, typename MtxView,
+          typename XView, typename ResView>
+__global__ __launch_bounds__(Config::waves *wave_size) void gemv_vec(
+    ArType alpha, MtxView mtx, XView x, ArType beta, ResView res)
+{
+    using ar_type = decltype(alpha * mtx(0, 0) * x(0, 0) + beta * res(0, 0));
+    static_assert(std::is_same<ArType, ar_type>::value,
+                  "accessor arithmetic must yield ArType");
+    using mtx_traits = view_traits<MtxView>;
+    using x_traits = view_traits<XView>;
+    using st_type = std::remove_cv_t<typename mtx_traits::storage_type>;
+    constexpr int R = Config::rows;
+    constexpr int U = Config::unroll;
+    constexpr int WPR = Config::wpr;
+    constexpr index_type wave_cols = index_type{wave_size} * Vec;
+    constexpr index_type iter_cols = wave_cols * WPR * U;
+
+    const int lane = lane_id();
+    const int wave = wave_id();
+    const int group = wave / WPR;
+    const int wave_in_group = wave % WPR;
+
+    const index_type num_rows = mtx.length(0);
+    const index_type num_cols = mtx.length(1);
+    const index_type row0 =
+        (index_type{blockIdx.x} * Config::groups + group) * R;
+
+    // Rows past the end are clamped to the last row for loading (keeps every
+    // access in bounds and every wave on the barrier path) and skipped when
+    // storing.
+    const st_type *row_ptr[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const index_type r =
+            (row0 + j < num_rows) ? row0 + j : num_rows - 1;
+        row_ptr[j] = mtx_traits::data(mtx) + r * mtx_traits::stride(mtx);
+    }
+    const st_type *x_ptr = x_traits::data(x);
+
+    ar_type acc[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        acc[j] = ar_type{};
+    }
+
+    // ---- main sweep: whole iterations, no bounds checks ------------------
+    const index_type main_cols = (num_cols / iter_cols) * iter_cols;
+    const index_type lane_off =
+        index_type{wave_in_group} * wave_cols + index_type{lane} * Vec;
+    for (index_type c0 = 0; c0 < main_cols; c0 += iter_cols) {
+        typename packed<st_type, Vec>::type xv[U];
+        typename packed<st_type, Vec>::type av[R][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const index_type c = c0 + index_type{u} * WPR * wave_cols + lane_off;
+            xv[u] = load_packed<Vec, false>(x_ptr + c);
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                av[j][u] = load_packed<Vec, Config::nt>(row_ptr[j] + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 0; k < Vec; ++k) {
+                const ar_type xk = static_cast<ar_type>(xv[u][k]);
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    acc[j] += static_cast<ar_type>(av[j][u][k]) * xk;
+                }
+            }
+        }
+    }
+
+    // ---- ragged end: chunk-wise, element-wise for the last partial chunk --
+    for (index_type c = main_cols + lane_off; c < num_cols;
+         c += WPR * wave_cols) {
+        if (c + Vec <= num_cols) {
+            const auto xv = load_packed<Vec, false>(x_ptr + c);
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const auto av = load_packed<Vec, Config::nt>(row_ptr[j] + c);
+#pragma unroll
+                for (int k = 0; k < Vec; ++k) {
+                    acc[j] += static_cast<ar_type>(av[k]) *
+                              static_cast<ar_type>(xv[k]);
+                }
+            }
+        } else {
+            for (index_type cc = c; cc < num_cols; ++cc) {
+                const ar_type xk = x(cc, 0);
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const index_type r =
+                        (row0 + j < num_rows) ? row0 + j : num_rows - 1;
+                    acc[j] += mtx(r, cc) * xk;
+                }
+            }
+        }
+    }
+
+    // ---- reduce: lanes by shuffle, waves of a group through LDS ----------
+    __shared__ ar_type scratch[Config::groups * R * WPR];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        acc[j] = wave_reduce_sum(acc[j]);
+    }
+    if (WPR > 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                scratch[(group * R + j) * WPR + wave_in_group] = acc[j];
+            }
+        }
+        __syncthreads();
+        // lane j of the group's first wave finishes row j
+        if (wave_in_group == 0 && lane < R) {
+            ar_type total{};
+#pragma unroll
+            for (int w = 0; w < WPR; ++w) {
+                total += scratch[(group * R + lane) * WPR + w];
+            }
+            const index_type row = row0 + lane;
+            if (row < num_rows) {
+                if (beta == ArType{0}) {
+                    res(row, 0) = alpha * total;
+                } else {
+                    res(row, 0) = alpha * total + beta * res(row, 0);
+                }
+            }
+        }
+    } else {
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const index_type row = row0 + j;
+                if (row < num_rows) {
+                    if (beta == ArType{0}) {
+                        res(row, 0) = alpha * acc[j];
+                    } else {
+                        res(row, 0) = alpha * acc[j] + beta * res(row, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+
+/**
+ * Fallback for any stride / alignment: one wave per row, lanes stride the
+ * columns, everything through `operator()` (4 independent loads per lane in
+ * flight). Same meaning as `cuda/gemv_kernels.cuh:79-113`.
+ */
+template <int Waves, typename ArType, typename MtxView, typename XView,
+          typename ResView>
+__global__ __launch_bounds__(Waves *wave_size) void gemv_generic(
+    ArType alpha, MtxView mtx, XView x, ArType beta, ResView res)
+{
+    using ar_type = decltype(alpha * mtx(0, 0) * x(0, 0) + beta * res(0, 0));
+    static_assert(std::is_same<ArType, ar_type>::value,
+                  "accessor arithmetic must yield ArType");
+    constexpr int U = 4;
+    const int lane = lane_id();
+    const index_type row = index_type{blockIdx.x} * Waves + wave_id();
+    const index_type num_cols = mtx.length(1);
+    if (row >= mtx.length(0)) {
+        return;
+    }
+    ar_type partial[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        partial[u] = ar_type{};
+    }
+    index_type col = lane;
+    for (; col + (U - 1) * wave_size < num_cols; col += U * wave_size) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            partial[u] +=
+                mtx(row, col + u * wave_size) * x(col + u * wave_size, 0);
+        }
+    }
+    for (; col < num_cols; col += wave_size) {
+        partial[0] += mtx(row, col) * x(col, 0);
+    }
+    ar_type sum = (partial[0] + partial[1]) + (partial[2] + partial[3]);
+    sum = wave_reduce_sum(sum);
+    if (lane == 0) {
+        if (beta == ArType{0}) {
+            res(row, 0) = alpha * sum;
+        } else {
+            res(row, 0) = alpha * sum + beta * res(row, 0);
+        }
+    }
+}
+
+
+}  // namespace kernel
+
+
+/** Production shape of the vector kernel (chosen by measurement on MI355X,
+ *  see DESIGN.md §GEMV). */
+using gemv_default_config = gemv_config<4, 4, 4, 2, false>;
+
+
+/**
+ * Picks the widest vector path the operands allow and launches. Returns the
+ * hipError_t of the launch.
+ */
+template <typename Config = gemv_default_config, typename ArType,
+          typename MtxView, typename XView, typename ResView>
+hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
+                       ArType beta, const ResView &res, hipStream_t stream)
+{
+    using mtx_traits = view_traits<MtxView>;
+    using x_traits = view_traits<XView>;
+    using st_type = std::remove_cv_t<typename mtx_traits::storage_type>;
+    constexpr int vec16 = 16 / sizeof(st_type);
+    constexpr int vec8 = 8 / sizeof(st_type);
+
+    const index_type rows = mtx.length(0);
+    if (rows <= 0) {
+        return hipSuccess;
+    }
+    const auto *a_ptr = mtx_traits::data(mtx);
+    const auto *x_ptr = x_traits::data(x);
+    const index_type lda = mtx_traits::stride(mtx);
+    const bool unit_x = x_traits::stride(x) == 1 || x.length(0) <= 1;
+
+    const dim3 block(Config::waves * wave_size, 1, 1);
+    const dim3 grid(
+        static_cast<unsigned>(ceildiv(rows, Config::rows_per_block)), 1, 1);
+    if (unit_x && lda % vec16 == 0 && is_aligned(a_ptr, 16) &&
+        is_aligned(x_ptr, 16)) {
+        kernel::gemv_vec<Config, vec16>
+            <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+    } else if (vec8 > 1 && unit_x && lda % vec8 == 0 &&
+               is_aligned(a_ptr, 8) && is_aligned(x_ptr, 8)) {
+        kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2)>
+            <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+    } else {
+        constexpr int waves = 4;
+        kernel::gemv_generic<waves>
+            <<<dim3(static_cast<unsigned>(ceildiv(rows, waves))),
+               dim3(waves * wave_size), 0, stream>>>(alpha, mtx, x, beta, res);
+    }
+    return hipGetLastError();
+}
+
+
+}  // namespace dev
+}  // namespace accblas

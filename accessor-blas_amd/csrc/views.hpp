@@ -1,0 +1,131 @@
+// Device-side views the kernels are written against.
+//
+// The reference has two kernel families per operation: plain pointers plus
+// `matrix_info` (`cuda/gemv_kernels.cuh:30-64`) and accessor ranges
+// (`:79-113`). Here ONE kernel template serves both: it is instantiated
+// either with `gko::acc::range<reduced_row_major<2, Ar, St>>` arguments
+// (the accessor path) or with `plain_view<V>` (pointer + sizes + stride, the
+// plain path). Both expose `length(d)` and `operator()(i, j)`; `view_traits`
+// adds what the 16-byte vector fast path needs (storage pointer + row
+// stride). Identical instruction order in both instantiations is what makes
+// "plain == Acc<T,T> bit for bit"  hold by construction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include <accessor/range.hpp>
+#include <accessor/reduced_row_major.hpp>
+
+
+namespace accblas {
+namespace dev {
+
+
+using index_type = std::int64_t;
+
+
+/** Row-major 2-D view over a plain pointer: element (i, j) = data[i*stride+j].
+ *  A vector with increment inc is the (n, 1) view with stride = inc, exactly
+ *  like the reference's `x[col * x_info.stride]` (`gemv_kernels.cuh:51`). */
+template <typename ValueType>
+struct plain_view {
+    using storage_type = ValueType;
+    using arithmetic_type = std::remove_cv_t<ValueType>;
+
+    ValueType *data;
+    index_type size[2];
+    index_type stride0;
+
+    __host__ __device__ __forceinline__ index_type length(index_type d) const
+    {
+        return d < 2 ? size[d] : 1;
+    }
+
+    __host__ __device__ __forceinline__ ValueType &operator()(
+        index_type i, index_type j) const
+    {
+        return data[i * stride0 + j];
+    }
+};
+
+
+template <typename View>
+struct view_traits;
+
+template <typename ValueType>
+struct view_traits<plain_view<ValueType>> {
+    using storage_type = ValueType;
+    using arithmetic_type = std::remove_cv_t<ValueType>;
+
+    __host__ __device__ static __forceinline__ ValueType *data(
+        const plain_view<ValueType> &v)
+    {
+        return v.data;
+    }
+    __host__ __device__ static __forceinline__ index_type stride(
+        const plain_view<ValueType> &v)
+    {
+        return v.stride0;
+    }
+};
+
+template <typename ArType, typename StType>
+struct view_traits<
+    gko::acc::range<gko::acc::reduced_row_major<2, ArType, StType>>> {
+    using range_type =
+        gko::acc::range<gko::acc::reduced_row_major<2, ArType, StType>>;
+    using storage_type = StType;
+    using arithmetic_type = std::remove_cv_t<ArType>;
+
+    __host__ __device__ static __forceinline__ StType *data(
+        const range_type &r)
+    {
+        return r->get_stored_data();
+    }
+    __host__ __device__ static __forceinline__ index_type stride(
+        const range_type &r)
+    {
+        return r->stride(0);
+    }
+};
+
+
+inline bool is_aligned(const void *ptr, std::size_t bytes)
+{
+    return reinterpret_cast<std::uintptr_t>(ptr) % bytes == 0;
+}
+
+__host__ __device__ constexpr index_type ceildiv(index_type a, index_type b)
+{
+    return (a + b - 1) / b;
+}
+
+
+/** N consecutive storage elements moved by ONE vector memory instruction
+ *  (16 bytes: 8 x fp16 / 4 x fp32 / 2 x fp64). */
+template <typename T, int N>
+struct packed {
+    typedef T type __attribute__((ext_vector_type(N)));
+};
+
+/** Streaming load of N storage elements; `ptr` must be N*sizeof(T) aligned.
+ *  NT = non-temporal hint (`global_load_dwordx4 ... nt`) for data that is
+ *  read exactly once (the matrix in GEMV/TRSV, both vectors in dot). */
+template <int N, bool NT, typename T>
+__device__ __forceinline__ typename packed<std::remove_cv_t<T>, N>::type
+load_packed(const T *ptr)
+{
+    using vec_type = typename packed<std::remove_cv_t<T>, N>::type;
+    const auto *vptr = reinterpret_cast<const vec_type *>(ptr);
+    if (NT) {
+        return __builtin_nontemporal_load(vptr);
+    }
+    return *vptr;
+}
+
+
+}  // namespace dev
+}  // namespace accblas

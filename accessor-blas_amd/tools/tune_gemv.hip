@@ -1,0 +1,121 @@
+// Developer tool (not part of the library): times gemv_vec shapes for
+// Acc<fp64 arithmetic, fp32 storage> at n x n on the current GPU, interleaved
+// rounds in one process (guide §5.4 rule 24). Usage: tune_gemv [n] [rounds]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "gemv_kernels.hpp"
+
+#define CHECK(call)                                                        \
+    do {                                                                   \
+        hipError_t e = (call);                                             \
+        if (e != hipSuccess) {                                             \
+            std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__,         \
+                         hipGetErrorString(e));                            \
+            std::exit(1);                                                  \
+        }                                                                  \
+    } while (0)
+
+using namespace accblas::dev;
+using ar_type = double;
+using st_type = float;
+using accessor = gko::acc::reduced_row_major<2, ar_type, st_type>;
+using range = gko::acc::range<accessor>;
+using c_range = gko::acc::range<accessor::const_accessor>;
+
+__global__ void fill(st_type *p, size_t n, unsigned seed)
+{
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned h = unsigned(i) * 2654435761u + seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (h & 0xffffff) / float(0x800000) - 1.0f;
+    }
+}
+
+struct entry {
+    std::string name;
+    std::function<void()> run;
+};
+
+template <typename Config>
+entry make(const char *name, c_range m, c_range x, range r)
+{
+    return {name, [=]() { CHECK(launch_gemv<Config>(1.0, m, x, 1.0, r, nullptr)); }};
+}
+
+int main(int argc, char **argv)
+{
+    const long n = argc > 1 ? std::atol(argv[1]) : 32768;
+    const int rounds = argc > 2 ? std::atoi(argv[2]) : 10;
+    st_type *A, *x, *res;
+    CHECK(hipMalloc(&A, size_t(n) * n * sizeof(st_type)));
+    CHECK(hipMalloc(&x, n * sizeof(st_type)));
+    CHECK(hipMalloc(&res, n * sizeof(st_type)));
+    fill<<<4096, 256>>>(A, size_t(n) * n, 1);
+    fill<<<64, 256>>>(x, n, 2);
+    CHECK(hipMemset(res, 0, n * sizeof(st_type)));
+    using sz = std::array<gko::acc::size_type, 2>;
+    using st = std::array<gko::acc::size_type, 1>;
+    c_range m(sz{{n, n}}, (const st_type *)A, st{{n}});
+    c_range xv(sz{{n, 1}}, (const st_type *)x, st{{1}});
+    range rv(sz{{n, 1}}, res, st{{1}});
+
+    std::vector<entry> entries = {
+        //            waves wpr rows unroll nt
+        make<gemv_config<4, 4, 4, 2, false>>("w4 wpr4 r4 u2", m, xv, rv),
+        make<gemv_config<4, 4, 4, 2, true>>("w4 wpr4 r4 u2 nt", m, xv, rv),
+        make<gemv_config<4, 1, 4, 2, false>>("w4 wpr1 r4 u2", m, xv, rv),
+        make<gemv_config<4, 1, 4, 2, true>>("w4 wpr1 r4 u2 nt", m, xv, rv),
+        make<gemv_config<4, 4, 2, 4, false>>("w4 wpr4 r2 u4", m, xv, rv),
+        make<gemv_config<4, 4, 8, 1, false>>("w4 wpr4 r8 u1", m, xv, rv),
+        make<gemv_config<4, 4, 8, 2, false>>("w4 wpr4 r8 u2", m, xv, rv),
+        make<gemv_config<8, 8, 4, 2, false>>("w8 wpr8 r4 u2", m, xv, rv),
+        make<gemv_config<8, 8, 4, 2, true>>("w8 wpr8 r4 u2 nt", m, xv, rv),
+        make<gemv_config<4, 4, 4, 4, false>>("w4 wpr4 r4 u4", m, xv, rv),
+        make<gemv_config<4, 4, 4, 1, false>>("w4 wpr4 r4 u1", m, xv, rv),
+        make<gemv_config<2, 2, 4, 2, false>>("w2 wpr2 r4 u2", m, xv, rv),
+        make<gemv_config<16, 16, 4, 2, false>>("w16 wpr16 r4 u2", m, xv, rv),
+        make<gemv_config<4, 2, 4, 2, false>>("w4 wpr2 r4 u2", m, xv, rv),
+        make<gemv_config<8, 1, 2, 4, false>>("w8 wpr1 r2 u4", m, xv, rv),
+        make<gemv_config<4, 4, 1, 8, false>>("w4 wpr4 r1 u8", m, xv, rv),
+    };
+    hipEvent_t start, stop;
+    CHECK(hipEventCreate(&start));
+    CHECK(hipEventCreate(&stop));
+    std::vector<std::vector<float>> times(entries.size());
+    for (auto &e : entries) {  // warm-up
+        e.run();
+    }
+    CHECK(hipDeviceSynchronize());
+    for (int r = 0; r < rounds; ++r) {
+        for (size_t i = 0; i < entries.size(); ++i) {
+            CHECK(hipEventRecord(start, nullptr));
+            entries[i].run();
+            CHECK(hipEventRecord(stop, nullptr));
+            CHECK(hipEventSynchronize(stop));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, start, stop));
+            times[i].push_back(ms);
+        }
+    }
+    const double bytes = sizeof(st_type) * (double(n) * n + 3.0 * n);
+    std::printf("n=%ld bytes=%.0f\n", n, bytes);
+    for (size_t i = 0; i < entries.size(); ++i) {
+        auto t = times[i];
+        std::sort(t.begin(), t.end());
+        const double mn = t.front(), med = t[t.size() / 2];
+        std::printf("%-22s min %8.3f us  med %8.3f us  -> %7.1f GB/s (min) %7.1f GB/s (med)\n",
+                    entries[i].name.c_str(), mn * 1e3, med * 1e3,
+                    bytes / (mn * 1e-3) / 1e9, bytes / (med * 1e-3) / 1e9);
+    }
+    return 0;
+}

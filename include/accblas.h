@@ -1,0 +1,183 @@
+/*
+ * accblas.h — C ABI of the MI355X (gfx950) accessor-BLAS hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one
+ * host launcher template (or runtime helper) of the reference's `cuda/` tree,
+ * cited per function as `file:line` relative to /root/reference. Host code
+ * (C++14, g++) never sees a HIP header: it includes this file and links
+ * libaccblas_hip.so. Conventions:
+ *   - every function returns an int status: 0 = ok, >0 = hipError_t value,
+ *     <0 = ACCBLAS_ERR_*; nothing throws across the boundary;
+ *     accblas_last_error_string() describes the last failure of the calling
+ *     thread;
+ *   - sizes, strides and increments are int64_t, counted in ELEMENTS;
+ *   - device buffers are opaque `void *` / `const void *` owned by the caller;
+ *   - alpha/beta travel as double and are narrowed to the arithmetic type
+ *     inside;
+ *   - `stream` is a hipStream_t passed as `void *`; NULL = the default stream;
+ *   - launches are asynchronous: the caller synchronises (as the reference's
+ *     `benchmark_function` does, cuda/utils.cuh:236-262).
+ * fp16 buffers hold IEEE binary16 bit patterns.
+ */
+#ifndef ACCBLAS_H_
+#define ACCBLAS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------ */
+#define ACCBLAS_OK 0
+#define ACCBLAS_ERR_UNSUPPORTED_TYPES (-1) /* (arithmetic, storage) pair not built */
+#define ACCBLAS_ERR_INVALID_ARGUMENT (-2)
+#define ACCBLAS_ERR_NULL_POINTER (-3)
+#define ACCBLAS_ERR_INTERNAL (-4)
+
+/* Element types. Storage: f16/f32/f64. Arithmetic: f32/f64. */
+typedef enum accblas_dtype {
+    ACCBLAS_F16 = 0,
+    ACCBLAS_F32 = 1,
+    ACCBLAS_F64 = 2
+} accblas_dtype;
+
+/* Mirrors `enum class tmtx_t { upper, lower }` (cuda/trsv_kernels.cuh:22). */
+typedef enum accblas_uplo { ACCBLAS_UPPER = 0, ACCBLAS_LOWER = 1 } accblas_uplo;
+
+/* Mirrors `enum class dmtx_t { non_unit, unit }` (cuda/trsv_kernels.cuh:29). */
+typedef enum accblas_diag {
+    ACCBLAS_NON_UNIT = 0,
+    ACCBLAS_UNIT = 1
+} accblas_diag;
+
+/* How the per-workgroup dot partials are combined. */
+typedef enum accblas_dot_mode {
+    /* one launch; partials -> workspace; the last workgroup to arrive sums
+     * them in a fixed order: bitwise reproducible (default) */
+    ACCBLAS_DOT_DETERMINISTIC = 0,
+    /* reference behaviour: zero the result, then one atomic_add per
+     * workgroup (cuda/dot_kernels.cuh:114,159; cuda/atomics.cuh:80-103) */
+    ACCBLAS_DOT_ATOMIC = 1
+} accblas_dot_mode;
+
+/* Replaces `myBlasHandle` (cuda/dot_kernels.cuh:29-65): cached device
+ * properties of the current device plus device scratch (dot partials, a
+ * 16-byte result slot, the 2-word TRSV helper). */
+typedef struct accblas_handle accblas_handle;
+
+/* ---- diagnostics ------------------------------------------------------- */
+const char *accblas_last_error_string(void);
+/* ABI version: major*10000 + minor*100 + patch */
+int accblas_version(void);
+size_t accblas_dtype_size(accblas_dtype t);
+
+/* ---- device / runtime (replaces cuda/utils.cuh:80-107, memory.cuh) ------ */
+int accblas_device_count(int *count);
+int accblas_set_device(int device);
+int accblas_get_device(int *device);
+/* name_len bytes are written at most (NUL terminated); any out pointer may
+ * be NULL */
+int accblas_device_info(int device, int *num_cus, int *wavefront_size,
+                        size_t *total_mem_bytes, char *name, size_t name_len);
+/* cudaDeviceSynchronize() of cuda/utils.cuh:107 */
+int accblas_device_synchronize(void);
+
+/* cudaMalloc / cudaFree / cudaMemcpy of cuda/memory.cuh:28-41,56-66,99-121 */
+int accblas_malloc(void **ptr, size_t bytes);
+int accblas_free(void *ptr);
+int accblas_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int accblas_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int accblas_memcpy_d2d(void *dst, const void *src, size_t bytes);
+int accblas_memset(void *dst, int value, size_t bytes);
+
+/* streams */
+int accblas_stream_create(void **stream);
+int accblas_stream_destroy(void *stream);
+int accblas_stream_synchronize(void *stream);
+
+/* events: `cuda_event` / `CudaTimer` of cuda/utils.cuh:113-182 */
+int accblas_event_create(void **event);
+int accblas_event_destroy(void *event);
+int accblas_event_record(void *event, void *stream);
+int accblas_event_synchronize(void *event);
+int accblas_event_elapsed_ms(float *ms, void *start, void *stop);
+
+/* ---- handle ------------------------------------------------------------ */
+int accblas_handle_create(accblas_handle **handle);
+int accblas_handle_destroy(accblas_handle *handle);
+/* number of compute units cached in the handle (multiProcessorCount of
+ * cuda/dot_kernels.cuh:199) */
+int accblas_handle_num_cus(const accblas_handle *handle, int *num_cus);
+int accblas_handle_set_dot_mode(accblas_handle *handle, accblas_dot_mode mode);
+/* 16-byte device scratch, `get_device_value_ptr` of cuda/dot_kernels.cuh:49-55 */
+int accblas_handle_device_scratch(accblas_handle *handle, void **ptr);
+/* 2 x uint32 device words usable as the TRSV helper */
+int accblas_handle_trsv_helper(accblas_handle *handle, uint32_t **helper);
+
+/* ---- GEMV: res = alpha * A * x + beta * res ------------------------------
+ * A row-major rows x cols with row stride lda (elements), x(i) = x[i*incx],
+ * res(i) = res[i*incres]. If beta == 0, res is not read. */
+
+/* `gemv<ValueType>` (cuda/gemv_kernels.cuh:136-147 -> kernel :30-64):
+ * plain-pointer kernel, everything in `vt`. */
+int accblas_gemv(accblas_dtype vt, int64_t rows, int64_t cols, double alpha,
+                 const void *A, int64_t lda, const void *x, int64_t incx,
+                 double beta, void *res, int64_t incres, void *stream);
+
+/* `acc_gemv<ArType, StType>` (cuda/gemv_kernels.cuh:168-193 -> kernel
+ * :79-113): kernel driven through range<reduced_row_major<2, ar, st>>:
+ * loads `st`, accumulates `ar`, stores `st`. */
+int accblas_acc_gemv(accblas_dtype ar, accblas_dtype st, int64_t rows,
+                     int64_t cols, double alpha, const void *A, int64_t lda,
+                     const void *x, int64_t incx, double beta, void *res,
+                     int64_t incres, void *stream);
+
+/* ---- DOT: *res = sum_i x[i*incx] * y[i*incy] -----------------------------
+ * `res` is a DEVICE scalar. */
+
+/* `dot<ValueType>` (cuda/dot_kernels.cuh:192-206 -> kernels :78-116). */
+int accblas_dot(accblas_handle *handle, accblas_dtype vt, int64_t n,
+                const void *x, int64_t incx, const void *y, int64_t incy,
+                void *res, void *stream);
+
+/* `acc_dot<ArType, StType, ResType>` (cuda/dot_kernels.cuh:224-263 ->
+ * kernels :131-173): loads `st`, accumulates `ar`, writes the device scalar
+ * as `res_t`. */
+int accblas_acc_dot(accblas_handle *handle, accblas_dtype ar, accblas_dtype st,
+                    accblas_dtype res_t, int64_t n, const void *x,
+                    int64_t incx, const void *y, int64_t incy, void *res,
+                    void *stream);
+
+/* ---- TRSV: x <- T^{-1} x in place ----------------------------------------
+ * T = upper/lower triangle of the row-major n x n matrix A (row stride lda),
+ * unit or non-unit diagonal. `helper` = 2 device uint32 words owned by the
+ * caller (cuda/trsv_benchmark.cu:98); NULL is not accepted. */
+
+/* `trsv<ValueType>` (cuda/trsv_kernels.cuh:455-488 -> kernels :38-42,
+ * :69-235, :263-432). */
+int accblas_trsv(accblas_dtype vt, accblas_uplo uplo, accblas_diag diag,
+                 int64_t n, const void *A, int64_t lda, void *x, int64_t incx,
+                 uint32_t *helper, void *stream);
+
+/* `acc_trsv<ArType, StType>` (cuda/trsv_kernels.cuh:918-961 -> kernels
+ * :527-692, :725-893). */
+int accblas_acc_trsv(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
+                     accblas_diag diag, int64_t n, const void *A, int64_t lda,
+                     void *x, int64_t incx, uint32_t *helper, void *stream);
+
+/* ---- helpers used by the benchmark setup -------------------------------- */
+
+/* Element-wise conversion on the device: dst[i] = static_cast<dst_t>(src[i]),
+ * i < n. The reference converts on the host (`convert_mtx`,
+ * cuda/matrix_helper.cuh:91-103); this is the same cast done in HBM so that
+ * large operands need not cross PCIe twice. */
+int accblas_convert(accblas_dtype dst_t, void *dst, accblas_dtype src_t,
+                    const void *src, int64_t n, void *stream);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* ACCBLAS_H_ */

@@ -1,0 +1,315 @@
+"""GPU parity tests: HIP kernels (through the C ABI) vs the CPU oracle.
+
+Run with `pytest -m gpu` on an MI355X. Metric and tolerances follow SURVEY.md
+§8d D4, check 1 (kernel parity on the SAME storage-rounded inputs, so only the
+summation order differs):
+  GEMV / TRSV: sum|oracle - hip| / sum|oracle|  (the reference's own `--error`
+  metric, `/root/reference/cuda/gemv_benchmark.cu:101-124`)
+      Ar=f64, f64 output ........ <= 1e-13
+      Ar=f64, f32 output ........ <= 1e-7   (rare 1-ulp(f32) flips)
+      Ar=f32, f32/f64 output .... <= 5e-6
+      any f16 output ............ <= 1e-3
+  DOT: |oracle - hip| <= 64 * eps(Ar) * Q, Q = sqrt(sum (x_i y_i)^2)
+  plain vs Acc<T,T>: exactly 0 (bit for bit).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as oracle
+from oracle_lib import F16, F32, F64
+
+pytestmark = pytest.mark.gpu
+
+PAIRS = [(F64, F64), (F64, F32), (F32, F32), (F64, F16), (F32, F16), (F32, F64)]
+EPS = {F32: 2.0 ** -24, F64: 2.0 ** -53}
+
+
+def out_tolerance(ar, st):
+    if st == F16:
+        return 1e-3
+    if ar == F64 and st == F64:
+        return 1e-13
+    if ar == F64 and st == F32:
+        return 1e-7
+    return 5e-6
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import accblas
+    accblas.load()
+    assert torch.cuda.is_available()
+    return torch, accblas
+
+
+def to_dev(torch, arr):
+    return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+
+
+def make_inputs(seed, count, st):
+    rng = np.random.default_rng(seed)
+    return oracle.convert(rng.uniform(-1.0, 1.0, count), st)
+
+
+# --------------------------------------------------------------------------- GEMV
+GEMV_SHAPES = [
+    # rows, cols, lda, offset (elements the base pointers are shifted by)
+    (1, 1, 1, 0),
+    (37, 53, 64, 0),      # ragged columns, vector path
+    (100, 100, 24500 // 4 * 4, 0),
+    (513, 1000, 1024, 0),
+    (64, 4096, 4096, 0),
+    (2048, 2048, 2048, 0),
+    (130, 1027, 1031, 0),  # lda odd -> generic path
+    (200, 512, 520, 1),    # misaligned base -> narrower / generic path
+    (3, 70000, 70000, 0),  # few long rows
+]
+
+
+@pytest.mark.parametrize("ar,st", PAIRS)
+@pytest.mark.parametrize("rows,cols,lda,offset", GEMV_SHAPES)
+def test_acc_gemv_matches_oracle(gpu, ar, st, rows, cols, lda, offset):
+    torch, accblas = gpu
+    A = make_inputs(1, rows * lda + offset, st)
+    x = make_inputs(2, cols + offset, st)
+    res = make_inputs(3, rows, st)
+    alpha, beta = 1.0, 1.0
+    want = oracle.exact_gemv(ar, rows, cols, alpha, A[offset:], lda, x[offset:], 1, beta,
+                             res, 1)
+    dA, dx, dres = to_dev(torch, A), to_dev(torch, x), to_dev(torch, res)
+    accblas.acc_gemv(ar, st, rows, cols, alpha, dA[offset:], lda, dx[offset:], 1, beta,
+                     dres, 1)
+    torch.cuda.synchronize()
+    got = dres.cpu().numpy()
+    err = oracle.rel_error(want.astype(np.float64), got.astype(np.float64))
+    assert err <= out_tolerance(ar, st), (err, rows, cols)
+    # the order-faithful emulation of the CUDA kernel must agree to the same bar
+    emulated = oracle.ref_gemv(ar, rows, cols, alpha, A[offset:], lda, x[offset:], 1,
+                               beta, res, 1)
+    err2 = oracle.rel_error(emulated.astype(np.float64), got.astype(np.float64))
+    assert err2 <= out_tolerance(ar, st), (err2, rows, cols)
+
+
+@pytest.mark.parametrize("vt", [F32, F64])
+@pytest.mark.parametrize("rows,cols,lda,offset", GEMV_SHAPES)
+def test_plain_gemv_equals_accessor_bitwise(gpu, vt, rows, cols, lda, offset):
+    """BASELINE config 2: plain-pointer kernel == Acc<T,T> kernel, bit for bit."""
+    torch, accblas = gpu
+    A = to_dev(torch, make_inputs(4, rows * lda + offset, vt))
+    x = to_dev(torch, make_inputs(5, cols + offset, vt))
+    res0 = make_inputs(6, rows, vt)
+    r_plain, r_acc = to_dev(torch, res0), to_dev(torch, res0)
+    accblas.gemv(vt, rows, cols, 1.0, A[offset:], lda, x[offset:], 1, 1.0, r_plain, 1)
+    accblas.acc_gemv(vt, vt, rows, cols, 1.0, A[offset:], lda, x[offset:], 1, 1.0, r_acc,
+                     1)
+    torch.cuda.synchronize()
+    assert torch.equal(r_plain, r_acc)
+    assert not torch.equal(r_plain, to_dev(torch, res0)) or cols == 0
+
+
+def test_gemv_beta_zero_does_not_read_res(gpu):
+    """beta == 0 must skip the read (`cuda/gemv_kernels.cuh:58-59,107-108`)."""
+    torch, accblas = gpu
+    rows, cols = 300, 700
+    A = make_inputs(7, rows * cols, F32)
+    x = make_inputs(8, cols, F32)
+    res = np.full(rows, np.nan, dtype=np.float32)
+    want = oracle.exact_gemv(F64, rows, cols, 0.5, A, cols, x, 1, 0.0, res, 1)
+    dres = to_dev(torch, res)
+    accblas.acc_gemv(F64, F32, rows, cols, 0.5, to_dev(torch, A), cols, to_dev(torch, x),
+                     1, 0.0, dres, 1)
+    torch.cuda.synchronize()
+    got = dres.cpu().numpy()
+    assert np.all(np.isfinite(got))
+    assert oracle.rel_error(want.astype(np.float64), got.astype(np.float64)) <= 1e-7
+
+
+def test_gemv_strided_vectors(gpu):
+    """x and res with increments != 1 (`x[col * x_info.stride]`, gemv_kernels.cuh:51)."""
+    torch, accblas = gpu
+    rows, cols, incx, incres = 257, 333, 3, 2
+    A = make_inputs(9, rows * cols, F32)
+    x = make_inputs(10, cols * incx, F32)
+    res = make_inputs(11, rows * incres, F32)
+    want = oracle.exact_gemv(F64, rows, cols, -1.5, A, cols, x, incx, 0.25, res, incres)
+    dres = to_dev(torch, res)
+    accblas.acc_gemv(F64, F32, rows, cols, -1.5, to_dev(torch, A), cols, to_dev(torch, x),
+                     incx, 0.25, dres, incres)
+    torch.cuda.synchronize()
+    got = dres.cpu().numpy()
+    # untouched gaps stay untouched
+    mask = np.ones(rows * incres, dtype=bool)
+    mask[::incres] = False
+    assert np.array_equal(got[mask], res[mask])
+    err = oracle.rel_error(want[::incres].astype(np.float64),
+                           got[::incres].astype(np.float64))
+    assert err <= 1e-7
+
+
+def test_gemv_empty_and_errors(gpu):
+    torch, accblas = gpu
+    dummy = torch.zeros(4, dtype=torch.float32, device="cuda")
+    accblas.acc_gemv(F64, F32, 0, 0, 1.0, dummy, 1, dummy, 1, 1.0, dummy, 1)
+    accblas.acc_gemv(F64, F32, 0, 5, 1.0, dummy, 5, dummy, 1, 1.0, dummy, 1)
+    # rows > 0, cols == 0: res = beta * res
+    r = torch.tensor([2.0, 4.0], dtype=torch.float32, device="cuda")
+    accblas.acc_gemv(F64, F32, 2, 0, 1.0, dummy, 1, dummy, 1, 0.5, r, 1)
+    torch.cuda.synchronize()
+    assert r.tolist() == [1.0, 2.0]
+    with pytest.raises(accblas.AccblasError) as info:
+        accblas.acc_gemv(F64, F32, 2, 4, 1.0, dummy, 3, dummy, 1, 1.0, dummy, 1)
+    assert info.value.status == -2
+    with pytest.raises(accblas.AccblasError) as info:
+        accblas.acc_gemv(F16, F32, 2, 2, 1.0, dummy, 2, dummy, 1, 1.0, dummy, 1)
+    assert info.value.status == -1
+
+
+# ---------------------------------------------------------------------------- DOT
+DOT_SIZES = [0, 1, 7, 64, 1000, 4099, 1_000_000, (1 << 22) + 3]
+
+
+@pytest.mark.parametrize("ar,st", PAIRS)
+@pytest.mark.parametrize("n", DOT_SIZES)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_acc_dot_matches_oracle(gpu, ar, st, n, mode):
+    torch, accblas = gpu
+    handle = accblas.Handle()
+    handle.set_dot_mode(mode)
+    x = make_inputs(20, max(n, 1), st)
+    y = make_inputs(21, max(n, 1), st)
+    want, scale = oracle.exact_dot(ar, n, x, 1, y, 1)
+    res = torch.full((1,), -999.0, dtype=accblas.torch_dtype(ar), device="cuda")
+    dx, dy = to_dev(torch, x), to_dev(torch, y)
+    accblas.acc_dot(handle, ar, st, ar, n, dx, 1, dy, 1, res)
+    torch.cuda.synchronize()
+    got = float(res.item())
+    assert abs(got - want) <= 64 * EPS[ar] * scale + 1e-300, (got, want, scale)
+    if mode == 0:
+        # deterministic mode: bitwise reproducible
+        res2 = torch.full((1,), -1.0, dtype=accblas.torch_dtype(ar), device="cuda")
+        accblas.acc_dot(handle, ar, st, ar, n, dx, 1, dy, 1, res2)
+        torch.cuda.synchronize()
+        assert torch.equal(res, res2)
+    handle.close()
+
+
+@pytest.mark.parametrize("vt", [F32, F64])
+def test_plain_dot_equals_accessor_bitwise(gpu, vt):
+    torch, accblas = gpu
+    handle = accblas.Handle()
+    n = 777_777
+    dx, dy = to_dev(torch, make_inputs(22, n, vt)), to_dev(torch, make_inputs(23, n, vt))
+    r1 = torch.zeros(1, dtype=accblas.torch_dtype(vt), device="cuda")
+    r2 = torch.zeros(1, dtype=accblas.torch_dtype(vt), device="cuda")
+    accblas.dot(handle, vt, n, dx, 1, dy, 1, r1)
+    accblas.acc_dot(handle, vt, vt, vt, n, dx, 1, dy, 1, r2)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r2)
+    handle.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_acc_dot_result_type_and_strides(gpu, mode):
+    """ResType != ArType (`cast_result`, dot_kernels.cuh:245-262) and increments."""
+    torch, accblas = gpu
+    handle = accblas.Handle()
+    handle.set_dot_mode(mode)
+    n, incx, incy = 50_001, 2, 3
+    x = make_inputs(24, n * incx, F32)
+    y = make_inputs(25, n * incy, F32)
+    want, scale = oracle.exact_dot(F64, n, x, incx, y, incy)
+    res = torch.zeros(1, dtype=torch.float32, device="cuda")
+    accblas.acc_dot(handle, F64, F32, F32, n, to_dev(torch, x), incx, to_dev(torch, y),
+                    incy, res)
+    torch.cuda.synchronize()
+    assert float(res.item()) == np.float32(want) or \
+        abs(float(res.item()) - want) <= 2.0 ** -23 * abs(want) + 64 * EPS[F64] * scale
+    handle.close()
+
+
+# --------------------------------------------------------------------------- TRSV
+def triangular_system(n, lda, upper, seed):
+    """Well-conditioned unit-bounded triangular factor as the reference builds it:
+    partial-pivot LU of a U(-1,1) matrix (`cuda/trsv_memory.cuh:131-168`), the
+    bounded unit factor placed in the requested triangle, the opposite triangle
+    filled with junk that must never be read as part of T, and a diagonal in
+    [1, 2) for the non-unit case."""
+    import scipy.linalg
+    rng = np.random.default_rng(seed)
+    dense = rng.uniform(-1.0, 1.0, (n, n))
+    _, lower, _ = scipy.linalg.lu(dense)
+    strict = np.tril(lower, -1)
+    diag = rng.uniform(1.0, 2.0, n)
+    full = rng.uniform(-1.0, 1.0, (n, lda))
+    tri = strict.T if upper else strict
+    mask = np.triu(np.ones((n, n), dtype=bool), 1) if upper else \
+        np.tril(np.ones((n, n), dtype=bool), -1)
+    full[:, :n][mask] = tri[mask]
+    full[np.arange(n), np.arange(n)] = diag
+    return full.reshape(-1)
+
+
+TRSV_SIZES = [(1, 1), (31, 40), (64, 64), (65, 100), (100, 24000 // 8), (1000, 1000),
+              (2050, 2112)]
+
+
+@pytest.mark.parametrize("ar,st", [(F64, F64), (F64, F32), (F32, F32), (F64, F16)])
+@pytest.mark.parametrize("upper", [False, True])
+@pytest.mark.parametrize("unit", [False, True])
+@pytest.mark.parametrize("n,lda", TRSV_SIZES)
+def test_acc_trsv_matches_oracle(gpu, ar, st, upper, unit, n, lda):
+    torch, accblas = gpu
+    A = oracle.convert(triangular_system(n, lda, upper, 30 + n), st)
+    b = make_inputs(31, n, st)
+    want = oracle.exact_trsv(ar, upper, unit, n, A, lda, b, 1)
+    dA, dx = to_dev(torch, A), to_dev(torch, b)
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    accblas.acc_trsv(ar, st, accblas.UPPER if upper else accblas.LOWER,
+                     accblas.UNIT if unit else accblas.NON_UNIT, n, dA, lda, dx, 1, helper)
+    torch.cuda.synchronize()
+    got = dx.cpu().numpy()
+    err = oracle.rel_error(want.astype(np.float64), got.astype(np.float64))
+    # a triangular solve amplifies rounding by the factor's condition number;
+    # the LU-derived factors used here keep that within ~1e2
+    assert err <= 100 * out_tolerance(ar, st), (err, n)
+    emulated = oracle.ref_trsv(ar, upper, unit, n, A, lda, b, 1)
+    err2 = oracle.rel_error(emulated.astype(np.float64), got.astype(np.float64))
+    assert err2 <= 100 * out_tolerance(ar, st), (err2, n)
+
+
+@pytest.mark.parametrize("vt", [F32, F64])
+@pytest.mark.parametrize("upper", [False, True])
+def test_plain_trsv_equals_accessor_bitwise(gpu, vt, upper):
+    torch, accblas = gpu
+    n, lda = 1500, 1536
+    A = to_dev(torch, oracle.convert(triangular_system(n, lda, upper, 77), vt))
+    b = make_inputs(32, n, vt)
+    x1, x2 = to_dev(torch, b), to_dev(torch, b)
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    uplo = accblas.UPPER if upper else accblas.LOWER
+    accblas.trsv(vt, uplo, accblas.UNIT, n, A, lda, x1, 1, helper)
+    accblas.acc_trsv(vt, vt, uplo, accblas.UNIT, n, A, lda, x2, 1, helper)
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x2)
+
+
+def test_trsv_manufactured_solution_strided(gpu):
+    """b = T x_true formed in high precision; the solve returns x_true
+    (SURVEY.md §8c C-4), with incx != 1."""
+    torch, accblas = gpu
+    n, lda, incx = 777, 800, 2
+    A = triangular_system(n, lda, False, 5)
+    T = np.tril(A.reshape(n, lda)[:, :n].astype(np.longdouble))
+    x_true = np.random.default_rng(6).uniform(-1, 1, n)
+    b = (T @ x_true.astype(np.longdouble)).astype(np.float64)
+    xb = np.zeros(n * incx)
+    xb[::incx] = b
+    dx = to_dev(torch, xb)
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    accblas.acc_trsv(F64, F64, accblas.LOWER, accblas.NON_UNIT, n, to_dev(torch, A), lda,
+                     dx, incx, helper)
+    torch.cuda.synchronize()
+    got = dx.cpu().numpy()
+    assert np.all(got[1::incx] == 0.0)
+    assert oracle.rel_error(x_true, got[::incx]) <= 1e-11
