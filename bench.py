@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GEMV through range<reduced_row_major<2, fp64, fp32>>.
+
+Workload (BASELINE.json north_star target, config "GEMV 32768x32768,
+storage=fp32 arithmetic=fp64"): res = alpha*A*x + beta*res with alpha=beta=1
+(`/root/reference/cuda/gemv_benchmark.cu:25-28`), A row-major n x n fp32 in HBM,
+arithmetic in fp64, `acc_gemv<double, float>` (`cuda/gemv_kernels.cuh:168-193`).
+A "step" is one such GEMV. Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1: GEMV shards by row blocks with NO data-path collective (SURVEY.md §8e
+E1): rank g owns rows [g*n, (g+1)*n) of a (N*n) x n matrix, a replica of x and
+its slice of res ("weak" scaling: fixed work per GPU). One process per GPU,
+torch.distributed (RCCL) only for the barrier and the max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (see the keys below). Conventions: flops = 2*n^2
+per GEMV, algorithmic bytes = s*(n^2 + 3n), s = sizeof(storage) (SURVEY.md §8d
+D3); HBM peak 8 TB/s.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(REPO, "accessor-blas_amd", "python"), os.path.join(REPO, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--n", type=int, default=32768, help="rows per GPU and columns")
+    p.add_argument("--st", default="f32", choices=["f16", "f32", "f64"])
+    p.add_argument("--ar", default="f64", choices=["f32", "f64"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(oracle, ar, A_rows, lda, x, res_rows, threads):
+    """Times the oracle's host-accessor GEMV on `A_rows` (a bounded sample of the
+    same workload): once on 1 thread (first 1/8 of the rows), once on all
+    threads. Returns (gflops_all, gflops_one, seconds_total, res_after)."""
+    import numpy as np
+    rows = res_rows.size
+    cols = x.size
+
+    def run(row_begin, row_end, nthreads, res):
+        bounds = np.linspace(row_begin, row_end, nthreads + 1).astype(np.int64)
+        workers = [threading.Thread(
+            target=oracle.accessor_gemv_rows,
+            args=(ar, int(bounds[i]), int(bounds[i + 1]), cols, 1.0, A_rows, lda, x, 1, 1.0,
+                  res, 1)) for i in range(nthreads)]
+        t0 = time.perf_counter()
+        for w in workers:
+            w.start()
+        for w in workers:
+            w.join()
+        return time.perf_counter() - t0
+
+    res_all = res_rows.copy()
+    t_all = min(run(0, rows, threads, res_all.copy()) for _ in range(2))
+    res_all = res_rows.copy()
+    run(0, rows, threads, res_all)  # keep one clean result for the parity check
+    one_rows = max(rows // 8, 1)
+    t_one = run(0, one_rows, 1, res_rows.copy())
+    return (2.0 * rows * cols / t_all / 1e9, 2.0 * one_rows * cols / t_one / 1e9, res_all)
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    import accblas
+
+    accblas.load()  # fails loudly if the HIP library is missing; no fallback
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run "
+                     "(one process per GPU)")
+        sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=dev)
+
+    codes = {"f16": accblas.F16, "f32": accblas.F32, "f64": accblas.F64}
+    st, ar = codes[args.st], codes[args.ar]
+    st_bytes = accblas.DTYPE_BYTES[st]
+    n = args.n
+    rows, cols, lda = n, n, n
+
+    # ---- synthetic inputs, generated on the device (U(-1,1) fp64 master, then
+    # the reference's static_cast to the storage type, gemv_memory.cuh:92-97)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42 + rank)
+    stream = torch.cuda.current_stream()
+
+    def uniform(count, generator):
+        return torch.rand(count, dtype=torch.float64, device=dev, generator=generator) \
+            .mul_(2.0).sub_(1.0)
+
+    def to_storage(master):
+        out = torch.empty(master.numel(), dtype=accblas.torch_dtype(st), device=dev)
+        accblas.convert(st, out, accblas.F64, master, master.numel(), stream)
+        return out
+
+    gen_x = torch.Generator(device=dev)
+    gen_x.manual_seed(7)  # x is replicated: same on every rank
+    x64 = uniform(cols, gen_x)
+    res64 = uniform(rows, gen)
+    A64 = uniform(rows * lda, gen)
+    A_st, x_st, res0_st = to_storage(A64), to_storage(x64), to_storage(res64)
+    torch.cuda.synchronize()
+
+    # ---- accuracy, untimed: the reference's --error metric against the GPU fp64
+    # plain kernel on the unrounded master data (gemv_benchmark.cu:219-232)
+    ref = res64.clone()
+    accblas.gemv(accblas.F64, rows, cols, 1.0, A64, lda, x64, 1, 1.0, ref, 1, stream)
+    res_st = res0_st.clone()
+    accblas.acc_gemv(ar, st, rows, cols, 1.0, A_st, lda, x_st, 1, 1.0, res_st, 1, stream)
+    torch.cuda.synchronize()
+    first_result = res_st.clone()
+    del A64
+    torch.cuda.empty_cache()
+
+    def step():
+        accblas.acc_gemv(ar, st, rows, cols, 1.0, A_st, lda, x_st, 1, 1.0, res_st, 1, stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev_start, ev_stop = accblas.Event(), accblas.Event()
+    barrier()
+    t0 = time.perf_counter()
+    ev_start.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev_stop.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev_start.elapsed_ms(ev_stop) / args.steps
+
+    if dist is not None:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    flops_per_step = 2.0 * rows * cols * world
+    bytes_per_launch = st_bytes * (rows * cols + 2.0 * rows + cols)
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "GEMV GFLOP/s + achieved HBM GB/s (% of peak) per (st_t,ar_t); "
+                  "dot rel-error",
+        "value": flops_per_step * args.steps / elapsed / 1e9,
+        "unit": "GFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.ar,
+        "data": "synthetic: U(-1,1) fp64 master drawn on the device (torch Philox), "
+                "static_cast to the storage type; alpha=beta=1",
+        "config": {
+            "workload": f"GEMV {rows}x{cols} per GPU, storage={args.st} "
+                        f"arithmetic={args.ar}, acc_gemv through "
+                        "range<reduced_row_major<2,ar,st>> (BASELINE configs[2], "
+                        "the north_star target)",
+            "rows_per_gpu": rows, "cols": cols, "lda": lda,
+            "sharding": "row blocks, x replicated, no collective" if world > 1 else "none",
+            "flops_per_gemv": "2*rows*cols",
+            "bytes_per_gemv": "s*(rows*cols + 2*rows + cols)",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "accblas::dev::kernel::gemv_vec",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel_us": kernel_ms * 1e3,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "achieved_gflops_per_gpu": 2.0 * rows * cols / (kernel_ms * 1e-3) / 1e9,
+        },
+    }
+    traffic_file = os.path.join(REPO, "profiles", "traffic.json")
+    if os.path.exists(traffic_file) and n == 32768 and args.st == "f32":
+        with open(traffic_file) as f:
+            out["roofline"]["traffic"] = json.load(f).get("gemv_vec_bytes_per_launch")
+
+    # ---- accuracy + CPU baseline on rank 0 (oracle = checker and baseline only)
+    import oracle_lib as oracle
+    ref_h = ref.cpu().numpy()
+    got_h = first_result.cpu().numpy()
+    out["rel_err_vs_fp64"] = oracle.rel_error(ref_h, got_h.astype(np.float64))
+    if world == 1 and not args.no_cpu_baseline:
+        threads = os.cpu_count() or 1
+        sample_rows = min(rows, 4096)
+        A_rows = A_st[: sample_rows * lda].cpu().numpy()
+        x_h = x_st.cpu().numpy()
+        res_rows = res0_st[:sample_rows].cpu().numpy()
+        g_all, g_one, res_cpu = cpu_baseline(oracle, ar, A_rows, lda, x_h, res_rows, threads)
+        out["cpu_baseline"] = {
+            "value": g_all,
+            "unit": "GFLOP/s",
+            "cores": threads,
+            "kind": "port",
+            "single_core_value": g_one,
+            "sample": f"oracle host-accessor GEMV (same kernel maths, Ar={args.ar} "
+                      f"St={args.st}) on the first {sample_rows} of {rows} rows of the "
+                      f"same matrix, {threads} threads by row blocks; single_core_value "
+                      f"= 1 thread on {max(sample_rows // 8, 1)} rows",
+        }
+        # the reference's own CPU path: compare + pairwise reduce on the result
+        t0 = time.perf_counter()
+        for _ in range(20):
+            oracle.compare(ref_h, got_h)
+        out["cpu_baseline"]["reference_error_check_us"] = \
+            (time.perf_counter() - t0) / 20 * 1e6
+        out["parity_sample_rel_err_vs_oracle"] = oracle.rel_error(
+            res_cpu.astype(np.float64), got_h[:sample_rows].astype(np.float64))
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
