@@ -788,3 +788,18 @@ int oracle_accessor_dot_chunk(int ar, int st, size_type begin, size_type end,
 
 
 }  // extern "C"
+
+
+// Advances the generator exactly as gen_mtx would for `count` values without
+// storing them (used to reach the draw positions of x / res behind a large A,
+// cuda/gemv_memory.cuh:45-47, without allocating A).
+extern "C" void oracle_engine_discard(void *engine, std::int64_t count)
+{
+    auto *box = static_cast<engine_box *>(engine);
+    for (std::int64_t i = 0; i < count; ++i) {
+        double val{};
+        do {
+            val = box->dist(box->engine);
+        } while (!std::isnormal(val));
+    }
+}

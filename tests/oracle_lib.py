@@ -41,6 +41,7 @@ def load():
         "oracle_engine_create": (_vp, [ctypes.c_uint32]),
         "oracle_engine_destroy": (None, [_vp]),
         "oracle_gen_mtx": (_int, [_vp, _i64, _i64, _i64, _vp]),
+        "oracle_engine_discard": (None, [_vp, _i64]),
         "oracle_write_random": (None, [_vp, _i64, _i64, _i64, _vp]),
         "oracle_convert": (_int, [_int, _vp, _int, _vp, _i64]),
         "oracle_reduce": (_dbl, [_i64, _i64, _vp, _int]),
@@ -94,6 +95,10 @@ class Engine:
         if status != 0:
             raise RuntimeError("Wrong use of stride")
         return out
+
+    def discard(self, count):
+        """Draws `count` values as gen_mtx would, without storing them."""
+        load().oracle_engine_discard(self._e, count)
 
     def write_random(self, out, rows, cols, stride=None):
         """`write_random` (`cuda/matrix_helper.cuh:66-76`)."""

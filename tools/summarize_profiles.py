@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 CSVs that tools/gpu_profile.sh left under gpurun_out/
+into the tracked summaries under profiles/ (round tag as argv[1], e.g. r01)."""
+import csv
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+OUT = os.path.join(REPO, "gpurun_out")
+PROF = os.path.join(REPO, "profiles")
+
+
+def counter_mean(directory, counter, needle):
+    path = os.path.join(OUT, directory, "gemv_counter_collection.csv")
+    values = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+              if r["Counter_Name"] == counter and needle in r["Kernel_Name"]
+              and "reduced_row_major" in r["Kernel_Name"]]
+    return sum(values) / len(values), len(values)
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    os.makedirs(PROF, exist_ok=True)
+    shutil.copy(os.path.join(OUT, "prof_stats", "gemv_kernel_stats.csv"),
+                os.path.join(PROF, f"{tag}_gemv_kernel_stats.csv"))
+    shutil.copy(os.path.join(OUT, "bench.json"), os.path.join(PROF, f"{tag}_bench.json"))
+    fetch_kb, n_fetch = counter_mean("prof_fetch", "FETCH_SIZE", "gemv_vec")
+    write_kb, n_write = counter_mean("prof_write", "WRITE_SIZE", "gemv_vec")
+    # MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
+    # FETCH_SIZE reports exactly half of the bytes of a 16-B/lane coalesced
+    # streaming read -> double it. WRITE_SIZE is taken as is.
+    read_bytes = 2.0 * fetch_kb * 1024.0
+    write_bytes = write_kb * 1024.0
+    bench = json.load(open(os.path.join(OUT, "bench.json")))
+    algorithmic = bench["roofline"]["algorithmic_bytes_per_launch"]
+    summary = {
+        "kernel": "accblas::dev::kernel::gemv_vec (Acc<fp64, fp32>, 32768x32768)",
+        "FETCH_SIZE_KiB_mean": fetch_kb, "fetch_dispatches": n_fetch,
+        "WRITE_SIZE_KiB_mean": write_kb, "write_dispatches": n_write,
+        "correction": "read bytes = 2 * FETCH_SIZE * 1024 (gfx950 wide-stream "
+                      "correction), write bytes = WRITE_SIZE * 1024; separate --pmc passes",
+        "gemv_vec_bytes_per_launch": read_bytes + write_bytes,
+        "algorithmic_bytes_per_launch": algorithmic,
+        "traffic_over_algorithmic": (read_bytes + write_bytes) / algorithmic,
+    }
+    with open(os.path.join(PROF, f"{tag}_gemv_pmc.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    with open(os.path.join(PROF, "traffic.json"), "w") as f:
+        json.dump({"source": f"profiles/{tag}_gemv_pmc.json",
+                   "gemv_vec_bytes_per_launch": read_bytes + write_bytes}, f, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
