@@ -1,0 +1,240 @@
+// Vendor columns and setup helpers (include/accblas_vendor.h): thin bindings of
+// rocBLAS / rocSOLVER behind the C ABI. Not on the hot path.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <string>
+
+#include "../../include/accblas_vendor.h"
+#include "accblas_internal.hpp"
+
+
+struct accblas_vendor_handle {
+    rocblas_handle blas;
+};
+
+
+namespace {
+
+
+int check_rocblas(rocblas_status status, const char *what)
+{
+    if (status == rocblas_status_success) {
+        return ACCBLAS_OK;
+    }
+    return accblas::set_error(
+        ACCBLAS_ERR_INTERNAL, std::string(what) + ": " +
+                                  rocblas_status_to_string(status));
+}
+
+int need_handle(const accblas_vendor_handle *handle)
+{
+    if (handle == nullptr) {
+        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER,
+                                  "vendor handle is NULL");
+    }
+    return ACCBLAS_OK;
+}
+
+
+}  // namespace
+
+
+extern "C" {
+
+
+int accblas_vendor_create(accblas_vendor_handle **handle)
+{
+    if (handle == nullptr) {
+        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER, "handle is NULL");
+    }
+    *handle = nullptr;
+    rocblas_handle blas;
+    const int status = check_rocblas(rocblas_create_handle(&blas),
+                                     "rocblas_create_handle");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    *handle = new accblas_vendor_handle{blas};
+    return ACCBLAS_OK;
+}
+
+int accblas_vendor_destroy(accblas_vendor_handle *handle)
+{
+    if (handle == nullptr) {
+        return ACCBLAS_OK;
+    }
+    const int status = check_rocblas(rocblas_destroy_handle(handle->blas),
+                                     "rocblas_destroy_handle");
+    delete handle;
+    return status;
+}
+
+int accblas_vendor_gemv(accblas_vendor_handle *handle, accblas_dtype vt,
+                        int64_t rows, int64_t cols, double alpha, const void *A,
+                        int64_t lda, const void *x, int64_t incx, double beta,
+                        void *res, int64_t incres)
+{
+    int status = need_handle(handle);
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    status = check_rocblas(
+        rocblas_set_pointer_mode(handle->blas, rocblas_pointer_mode_host),
+        "rocblas_set_pointer_mode");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    // row-major rows x cols == column-major cols x rows; y = op_T(A_cm) x
+    const auto m = static_cast<rocblas_int>(cols);
+    const auto n = static_cast<rocblas_int>(rows);
+    if (vt == ACCBLAS_F64) {
+        const double a = alpha, b = beta;
+        return check_rocblas(
+            rocblas_dgemv(handle->blas, rocblas_operation_transpose, m, n, &a,
+                          static_cast<const double *>(A),
+                          static_cast<rocblas_int>(lda),
+                          static_cast<const double *>(x),
+                          static_cast<rocblas_int>(incx), &b,
+                          static_cast<double *>(res),
+                          static_cast<rocblas_int>(incres)),
+            "rocblas_dgemv");
+    }
+    if (vt == ACCBLAS_F32) {
+        const float a = static_cast<float>(alpha), b = static_cast<float>(beta);
+        return check_rocblas(
+            rocblas_sgemv(handle->blas, rocblas_operation_transpose, m, n, &a,
+                          static_cast<const float *>(A),
+                          static_cast<rocblas_int>(lda),
+                          static_cast<const float *>(x),
+                          static_cast<rocblas_int>(incx), &b,
+                          static_cast<float *>(res),
+                          static_cast<rocblas_int>(incres)),
+            "rocblas_sgemv");
+    }
+    return accblas::set_error(ACCBLAS_ERR_UNSUPPORTED_TYPES,
+                              "vendor gemv: f32 / f64 only");
+}
+
+int accblas_vendor_dot(accblas_vendor_handle *handle, accblas_dtype vt,
+                       int64_t n, const void *x, int64_t incx, const void *y,
+                       int64_t incy, void *res)
+{
+    int status = need_handle(handle);
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    status = check_rocblas(
+        rocblas_set_pointer_mode(handle->blas, rocblas_pointer_mode_device),
+        "rocblas_set_pointer_mode");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    if (vt == ACCBLAS_F64) {
+        return check_rocblas(
+            rocblas_ddot(handle->blas, static_cast<rocblas_int>(n),
+                         static_cast<const double *>(x),
+                         static_cast<rocblas_int>(incx),
+                         static_cast<const double *>(y),
+                         static_cast<rocblas_int>(incy),
+                         static_cast<double *>(res)),
+            "rocblas_ddot");
+    }
+    if (vt == ACCBLAS_F32) {
+        return check_rocblas(
+            rocblas_sdot(handle->blas, static_cast<rocblas_int>(n),
+                         static_cast<const float *>(x),
+                         static_cast<rocblas_int>(incx),
+                         static_cast<const float *>(y),
+                         static_cast<rocblas_int>(incy),
+                         static_cast<float *>(res)),
+            "rocblas_sdot");
+    }
+    return accblas::set_error(ACCBLAS_ERR_UNSUPPORTED_TYPES,
+                              "vendor dot: f32 / f64 only");
+}
+
+int accblas_vendor_trsv(accblas_vendor_handle *handle, accblas_dtype vt,
+                        accblas_uplo uplo, accblas_diag diag, int64_t n,
+                        const void *A, int64_t lda, void *x, int64_t incx)
+{
+    const int status = need_handle(handle);
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    // the column-major view of a row-major upper triangle is lower, and the
+    // solve needs the transposed operation
+    const rocblas_fill fill =
+        uplo == ACCBLAS_UPPER ? rocblas_fill_lower : rocblas_fill_upper;
+    const rocblas_diagonal d = diag == ACCBLAS_UNIT ? rocblas_diagonal_unit
+                                                    : rocblas_diagonal_non_unit;
+    if (vt == ACCBLAS_F64) {
+        return check_rocblas(
+            rocblas_dtrsv(handle->blas, fill, rocblas_operation_transpose, d,
+                          static_cast<rocblas_int>(n),
+                          static_cast<const double *>(A),
+                          static_cast<rocblas_int>(lda),
+                          static_cast<double *>(x),
+                          static_cast<rocblas_int>(incx)),
+            "rocblas_dtrsv");
+    }
+    if (vt == ACCBLAS_F32) {
+        return check_rocblas(
+            rocblas_strsv(handle->blas, fill, rocblas_operation_transpose, d,
+                          static_cast<rocblas_int>(n),
+                          static_cast<const float *>(A),
+                          static_cast<rocblas_int>(lda),
+                          static_cast<float *>(x),
+                          static_cast<rocblas_int>(incx)),
+            "rocblas_strsv");
+    }
+    return accblas::set_error(ACCBLAS_ERR_UNSUPPORTED_TYPES,
+                              "vendor trsv: f32 / f64 only");
+}
+
+int accblas_vendor_getrf(accblas_vendor_handle *handle, int64_t n, void *A,
+                         int64_t lda, int *info)
+{
+    int status = need_handle(handle);
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    if (n <= 0) {
+        return ACCBLAS_OK;
+    }
+    rocblas_int *pivots = nullptr;
+    rocblas_int *dev_info = nullptr;
+    status = accblas::check_hip(
+        hipMalloc(&pivots, sizeof(rocblas_int) * static_cast<size_t>(n)),
+        "hipMalloc(pivots)");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    status = accblas::check_hip(hipMalloc(&dev_info, sizeof(rocblas_int)),
+                                "hipMalloc(info)");
+    if (status == ACCBLAS_OK) {
+        status = check_rocblas(
+            rocsolver_dgetrf(handle->blas, static_cast<rocblas_int>(n),
+                             static_cast<rocblas_int>(n),
+                             static_cast<double *>(A),
+                             static_cast<rocblas_int>(lda), pivots, dev_info),
+            "rocsolver_dgetrf");
+    }
+    if (status == ACCBLAS_OK) {
+        rocblas_int host_info = 0;
+        status = accblas::check_hip(
+            hipMemcpy(&host_info, dev_info, sizeof(host_info),
+                      hipMemcpyDeviceToHost),
+            "hipMemcpy(info)");
+        if (info != nullptr) {
+            *info = host_info;
+        }
+    }
+    (void)hipFree(pivots);
+    (void)hipFree(dev_info);
+    return status;
+}
+
+
+}  // extern "C"
