@@ -265,7 +265,9 @@ int accblas_handle_create(accblas_handle **handle)
     }
     constexpr size_t partial_bytes =
         size_t{accblas::dev::dot_max_partials} * sizeof(double);
-    constexpr size_t total_bytes = partial_bytes + 3 * 16;
+    constexpr size_t ticket_bytes =
+        size_t{accblas::dev::dot_ticket_words} * sizeof(unsigned int);
+    constexpr size_t total_bytes = partial_bytes + ticket_bytes + 2 * 16;
     void *workspace = nullptr;
     status = check_hip(hipMalloc(&workspace, total_bytes), "hipMalloc");
     if (status != ACCBLAS_OK) {
@@ -284,10 +286,10 @@ int accblas_handle_create(accblas_handle **handle)
     auto *bytes = static_cast<char *>(workspace);
     h->dot_ws.partials = bytes;
     h->dot_ws.ticket = reinterpret_cast<unsigned int *>(bytes + partial_bytes);
-    h->dot_ws.scalar = bytes + partial_bytes + 16;
+    h->dot_ws.scalar = bytes + partial_bytes + ticket_bytes;
     h->dot_ws.num_cus = h->num_cus;
     h->trsv_helper =
-        reinterpret_cast<std::uint32_t *>(bytes + partial_bytes + 32);
+        reinterpret_cast<std::uint32_t *>(bytes + partial_bytes + ticket_bytes + 16);
     *handle = h;
     return ACCBLAS_OK;
 }

@@ -2,12 +2,63 @@
 // reference launchers do (`/root/reference/cuda/trsv_kernels.cuh:455-488`
 // plain, `:918-961` accessor).
 #include <array>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "accblas_internal.hpp"
 #include "trsv_kernels.hpp"
 
 
 namespace {
+
+
+// Hand-off workspace of the solve kernel (8-byte {tag, value} granules, one or
+// two per element of x). The reference's launcher signature has no handle to
+// keep it in, so the library owns one buffer per (device, stream) and grows it
+// on demand; growth is the only time a TRSV call allocates (and synchronises
+// that stream first, so a solve still reading the old buffer finishes).
+struct workspace_entry {
+    void *ptr{nullptr};
+    std::size_t bytes{0};
+};
+
+int get_workspace(hipStream_t stream, std::size_t bytes,
+                  accblas::dev::granule_word **out)
+{
+    static std::mutex guard;
+    static std::map<std::pair<int, hipStream_t>, workspace_entry> cache;
+    int device = 0;
+    int status = accblas::check_hip(hipGetDevice(&device), "hipGetDevice");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    std::lock_guard<std::mutex> lock(guard);
+    auto &entry = cache[std::make_pair(device, stream)];
+    if (entry.bytes < bytes) {
+        if (entry.ptr != nullptr) {
+            status = accblas::check_hip(hipStreamSynchronize(stream),
+                                        "hipStreamSynchronize");
+            if (status != ACCBLAS_OK) {
+                return status;
+            }
+            (void)hipFree(entry.ptr);
+            entry = workspace_entry{};
+        }
+        const std::size_t rounded =
+            std::max<std::size_t>(bytes + bytes / 2, std::size_t{1} << 16);
+        status = accblas::check_hip(hipMalloc(&entry.ptr, rounded),
+                                    "hipMalloc(trsv workspace)");
+        if (status != ACCBLAS_OK) {
+            entry = workspace_entry{};
+            return status;
+        }
+        entry.bytes = rounded;
+    }
+    *out = static_cast<accblas::dev::granule_word *>(entry.ptr);
+    return ACCBLAS_OK;
+}
+
 
 
 int validate_trsv(accblas_uplo uplo, accblas_diag diag, int64_t n,
@@ -66,9 +117,16 @@ int accblas_trsv(accblas_dtype vt, accblas_uplo uplo, accblas_diag diag,
             static_cast<const value_type *>(A), {n, n}, lda};
         const plain_view<value_type> x_view{static_cast<value_type *>(x),
                                             {n, 1}, incx};
+        granule_word *granules = nullptr;
+        const int ws_status =
+            get_workspace(accblas::as_stream(stream),
+                          trsv_workspace_bytes<value_type>(n), &granules);
+        if (ws_status != ACCBLAS_OK) {
+            return ws_status;
+        }
         return accblas::check_hip(
             launch_trsv<value_type>(uplo == ACCBLAS_UPPER, diag == ACCBLAS_UNIT,
-                                    m_view, x_view, helper,
+                                    m_view, x_view, helper, granules,
                                     accblas::as_stream(stream)),
             "trsv launch");
     });
@@ -102,10 +160,17 @@ int accblas_acc_trsv(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
             const auto x_acc = range(size_array{{n, 1}},
                                      static_cast<st_type *>(x),
                                      stride_array{{incx}});
+            accblas::dev::granule_word *granules = nullptr;
+            const int ws_status = get_workspace(
+                accblas::as_stream(stream),
+                accblas::dev::trsv_workspace_bytes<st_type>(n), &granules);
+            if (ws_status != ACCBLAS_OK) {
+                return ws_status;
+            }
             return accblas::check_hip(
                 accblas::dev::launch_trsv<ar_type>(
                     uplo == ACCBLAS_UPPER, diag == ACCBLAS_UNIT, m_acc, x_acc,
-                    helper, accblas::as_stream(stream)),
+                    helper, granules, accblas::as_stream(stream)),
                 "acc_trsv launch");
         });
     });

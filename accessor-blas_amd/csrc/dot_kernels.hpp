@@ -31,9 +31,33 @@ namespace accblas {
 namespace dev {
 
 
-constexpr int dot_block_waves = 8;        // 512 threads
-constexpr int dot_blocks_per_cu = 4;      // persistent grid = CUs * this
 constexpr int dot_max_partials = 4096;    // workspace slots in the handle
+constexpr int dot_ticket_shards = 16;     // arrival counters, one 64 B line each
+constexpr int dot_ticket_words = (dot_ticket_shards + 1) * 16;  // + top counter
+
+
+/** Tuning knobs: waves per workgroup, independent load pairs per lane,
+ *  workgroups per CU of the persistent grid, and whether a workgroup sweeps a
+ *  contiguous slice of the vectors (true) or the whole grid strides together
+ *  (false). */
+template <int Waves, int Unroll, int BlocksPerCu, bool Contiguous>
+struct dot_config {
+    static constexpr int waves = Waves;
+    static constexpr int unroll = Unroll;
+    static constexpr int blocks_per_cu = BlocksPerCu;
+    static constexpr bool contiguous = Contiguous;
+};
+
+/** Production shapes, chosen by measurement on MI355X (tools/tune_dot.hip,
+ *  profiles/r01_tune_dot.txt): 512-thread workgroups, 4 load pairs per lane
+ *  in flight, 2 workgroups per CU. Streams beyond the Infinity Cache run
+ *  faster when each workgroup sweeps one contiguous slice (6.5 vs 6.2 TB/s at
+ *  2 x 1 GiB); smaller ones when the whole grid strides together (5.3 vs
+ *  5.0 TB/s at 2 x 64 MiB). */
+using dot_stride_config = dot_config<8, 4, 2, false>;
+using dot_contiguous_config = dot_config<8, 4, 2, true>;
+constexpr index_type dot_contiguous_min_bytes = index_type{1} << 29;
+struct dot_auto_config {};
 
 
 namespace kernel {
@@ -68,11 +92,13 @@ __global__ __launch_bounds__(64) void cast_result(const InType *in,
  * the last workgroup as ResType. Atomic == true: atomic_add(accum, partial)
  * as `cuda/dot_kernels.cuh:158-160` (accum must be zeroed before).
  */
-template <int Waves, int Vec, int Unroll, bool Atomic, typename XView,
+template <typename Config, int Vec, bool Atomic, typename XView,
           typename YView, typename ArType, typename ResType>
-__global__ __launch_bounds__(Waves *wave_size) void dot(
+__global__ __launch_bounds__(Config::waves *wave_size) void dot(
     XView x, YView y, ArType *partials, unsigned int *ticket, ResType *res)
 {
+    constexpr int Waves = Config::waves;
+    constexpr int Unroll = Config::unroll;
     using ar_type = decltype(x(0, 0) + y(0, 0));
     static_assert(std::is_same<ArType, ar_type>::value,
                   "accessor arithmetic must yield ArType");
@@ -84,7 +110,11 @@ __global__ __launch_bounds__(Waves *wave_size) void dot(
     const index_type n = x.length(0);
     const index_type tid =
         index_type{blockIdx.x} * block_threads + threadIdx.x;
-    const index_type num_threads = index_type{gridDim.x} * block_threads;
+    // grid-stride: all threads of the grid advance together; contiguous: each
+    // workgroup owns one slice [first, last) of the chunk range
+    const index_type num_threads =
+        Config::contiguous ? index_type{block_threads}
+                           : index_type{gridDim.x} * block_threads;
 
     ar_type acc[Unroll];
 #pragma unroll
@@ -95,8 +125,16 @@ __global__ __launch_bounds__(Waves *wave_size) void dot(
     if (Vec > 1) {
         const st_type *x_ptr = x_traits::data(x);
         const st_type *y_ptr = y_traits::data(y);
-        const index_type num_chunks = n / Vec;
-        index_type chunk = tid;
+        const index_type all_chunks = n / Vec;
+        const index_type per_block = ceildiv(all_chunks, gridDim.x);
+        const index_type first =
+            Config::contiguous ? index_type{blockIdx.x} * per_block : 0;
+        const index_type num_chunks =
+            Config::contiguous
+                ? (first + per_block < all_chunks ? first + per_block
+                                                  : all_chunks)
+                : all_chunks;
+        index_type chunk = Config::contiguous ? first + threadIdx.x : tid;
         // Unroll independent chunk pairs per lane per iteration
         for (; chunk + (Unroll - 1) * num_threads < num_chunks;
              chunk += Unroll * num_threads) {
@@ -128,21 +166,22 @@ __global__ __launch_bounds__(Waves *wave_size) void dot(
             }
         }
         // elements past the last whole chunk (< Vec of them)
-        const index_type tail = num_chunks * Vec + tid;
+        const index_type tail = all_chunks * Vec + tid;
         if (tail < n) {
             acc[0] += x(tail, 0) * y(tail, 0);
         }
     } else {
+        const index_type grid_threads = index_type{gridDim.x} * block_threads;
         index_type idx = tid;
-        for (; idx + (Unroll - 1) * num_threads < n;
-             idx += Unroll * num_threads) {
+        for (; idx + (Unroll - 1) * grid_threads < n;
+             idx += Unroll * grid_threads) {
 #pragma unroll
             for (int u = 0; u < Unroll; ++u) {
-                acc[u] += x(idx + u * num_threads, 0) *
-                          y(idx + u * num_threads, 0);
+                acc[u] += x(idx + u * grid_threads, 0) *
+                          y(idx + u * grid_threads, 0);
             }
         }
-        for (; idx < n; idx += num_threads) {
+        for (; idx < n; idx += grid_threads) {
             acc[0] += x(idx, 0) * y(idx, 0);
         }
     }
@@ -166,13 +205,27 @@ __global__ __launch_bounds__(Waves *wave_size) void dot(
 
     // publish the partial, then take a ticket (guide G16: sc1 payload ->
     // drain -> agent-scope atomic; the last arriver is told by the value its
-    // add returned)
+    // add returned). Same-address atomics retire at ~12 ns each, so arrivals
+    // are spread over dot_ticket_shards counters on separate 64 B lines; the
+    // last arriver of a shard then arrives at the top counter.
     if (threadIdx.x == 0) {
         store_agent(partials + blockIdx.x, block_sum);
         drain_vmem();
+        const unsigned int shard = blockIdx.x % dot_ticket_shards;
+        const unsigned int shard_size =
+            (gridDim.x - shard + dot_ticket_shards - 1) / dot_ticket_shards;
+        const unsigned int active_shards =
+            gridDim.x < dot_ticket_shards ? gridDim.x : dot_ticket_shards;
+        bool last = false;
         const unsigned int drawn = __hip_atomic_fetch_add(
-            ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (drawn == gridDim.x - 1);
+            ticket + 16 * (shard + 1), 1u, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+        if (drawn == shard_size - 1) {
+            const unsigned int top = __hip_atomic_fetch_add(
+                ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (top == active_shards - 1);
+        }
+        is_last = last;
     }
     __syncthreads();
     if (!is_last) {
@@ -188,8 +241,11 @@ __global__ __launch_bounds__(Waves *wave_size) void dot(
     total = block_reduce_sum<Waves>(total, scratch);
     if (threadIdx.x == 0) {
         *res = static_cast<ResType>(total);
-        // re-arm the ticket for the next call on this stream
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED,
+    }
+    // re-arm every counter for the next call on this stream (all arrivals of
+    // this launch have happened: this workgroup drew the last ticket)
+    if (threadIdx.x <= dot_ticket_shards) {
+        __hip_atomic_store(ticket + 16 * threadIdx.x, 0u, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -201,30 +257,33 @@ __global__ __launch_bounds__(Waves *wave_size) void dot(
 /** Device scratch of a handle that the dot launcher needs. */
 struct dot_workspace {
     void *partials;          // dot_max_partials * 8 bytes
-    unsigned int *ticket;    // zero between calls
+    unsigned int *ticket;    // dot_ticket_words words, zero between calls
     void *scalar;            // 16-byte slot (`get_device_value_ptr`)
     int num_cus;
 };
 
 
-template <typename ArType, typename ResType, typename XView, typename YView>
-hipError_t launch_dot(const dot_workspace &ws, bool atomic, const XView &x,
-                      const YView &y, ResType *res, hipStream_t stream)
+template <typename ArType, typename Config, typename ResType, typename XView,
+          typename YView>
+hipError_t launch_dot_with(const dot_workspace &ws, bool atomic,
+                           const XView &x, const YView &y, ResType *res,
+                           hipStream_t stream)
 {
     using x_traits = view_traits<XView>;
     using y_traits = view_traits<YView>;
     using st_type = std::remove_cv_t<typename x_traits::storage_type>;
     constexpr int vec16 = 16 / sizeof(st_type);
-    constexpr int unroll = 4;
-    constexpr int waves = dot_block_waves;
+    constexpr int waves = Config::waves;
 
     const index_type n = x.length(0);
-    int blocks = ws.num_cus * dot_blocks_per_cu;
+    int blocks = ws.num_cus * Config::blocks_per_cu;
     if (blocks > dot_max_partials) {
         blocks = dot_max_partials;
     }
-    // do not launch workgroups that would have nothing to do
-    const index_type per_block = index_type{waves} * wave_size * vec16;
+    // every workgroup should have at least two full unrolled iterations of
+    // work; smaller problems get a smaller grid (fewer arrivals to combine)
+    const index_type per_block =
+        index_type{waves} * wave_size * vec16 * Config::unroll * 2;
     const index_type needed = n > 0 ? (n + per_block - 1) / per_block : 1;
     if (needed < blocks) {
         blocks = static_cast<int>(needed);
@@ -244,10 +303,10 @@ hipError_t launch_dot(const dot_workspace &ws, bool atomic, const XView &x,
                                : static_cast<ArType *>(ws.scalar);
         kernel::init_res<<<1, 64, 0, stream>>>(accum);
         if (vec_ok) {
-            kernel::dot<waves, vec16, unroll, true>
+            kernel::dot<Config, vec16, true>
                 <<<grid, block, 0, stream>>>(x, y, accum, ws.ticket, res);
         } else {
-            kernel::dot<waves, 1, unroll, true>
+            kernel::dot<Config, 1, true>
                 <<<grid, block, 0, stream>>>(x, y, accum, ws.ticket, res);
         }
         if (!direct) {
@@ -255,14 +314,39 @@ hipError_t launch_dot(const dot_workspace &ws, bool atomic, const XView &x,
         }
     } else {
         if (vec_ok) {
-            kernel::dot<waves, vec16, unroll, false>
+            kernel::dot<Config, vec16, false>
                 <<<grid, block, 0, stream>>>(x, y, partials, ws.ticket, res);
         } else {
-            kernel::dot<waves, 1, unroll, false>
+            kernel::dot<Config, 1, false>
                 <<<grid, block, 0, stream>>>(x, y, partials, ws.ticket, res);
         }
     }
     return hipGetLastError();
+}
+
+
+/** Launches with an explicit Config, or (default) picks the production shape
+ *  from the amount of data streamed. */
+template <typename ArType, typename Config = dot_auto_config, typename ResType,
+          typename XView, typename YView>
+hipError_t launch_dot(const dot_workspace &ws, bool atomic, const XView &x,
+                      const YView &y, ResType *res, hipStream_t stream)
+{
+    if (!std::is_same<Config, dot_auto_config>::value) {
+        using chosen = std::conditional_t<
+            std::is_same<Config, dot_auto_config>::value, dot_stride_config,
+            Config>;
+        return launch_dot_with<ArType, chosen>(ws, atomic, x, y, res, stream);
+    }
+    using st_type = typename view_traits<XView>::storage_type;
+    const index_type bytes =
+        2 * static_cast<index_type>(sizeof(st_type)) * x.length(0);
+    if (bytes >= dot_contiguous_min_bytes) {
+        return launch_dot_with<ArType, dot_contiguous_config>(ws, atomic, x, y,
+                                                              res, stream);
+    }
+    return launch_dot_with<ArType, dot_stride_config>(ws, atomic, x, y, res,
+                                                      stream);
 }
 
 

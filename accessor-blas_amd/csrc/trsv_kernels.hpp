@@ -8,24 +8,33 @@
 // Dense Triangular Solve in CUDA"): ONE kernel, row blocks numbered by a
 // ticket drawn at start (a block only ever waits on blocks that are already
 // running, so no residency assumption), the diagonal tile inverted before the
-// block has to wait, a "last finished block" word that later blocks poll.
-// Re-designed for CDNA4:
-//   * tile = 64 x 64 (one wave = one tile row): half the sequential hops of
-//     the reference's 32-wide tiles;
-//   * upper and lower are one kernel: upper is solved as the lower problem of
-//     the index-reversed system (i' = n-1-i), which reproduces the reference's
+// block has to wait, later blocks consuming earlier solutions as they appear.
+// Re-designed for CDNA4 (the solve is a chain of n/64 dependent hops, so the
+// design minimises what sits between "x_{b-1} published" and "x_b published"):
+//   * tile = 64 x 64 (one wave = one tile row): half the hops of the
+//     reference's 32-wide tiles;
+//   * upper and lower are one kernel: upper is the lower problem of the
+//     index-reversed system (i' = n-1-i), which reproduces the reference's
 //     bottom-up block numbering with the ragged block at the top;
-//   * the tile inverse is computed by ONE wave with each lane owning a column
-//     of the inverse in registers (2016 FMAs, no synchronisation), instead of
-//     a Gauss-Jordan sweep through shared memory with a sync per step;
-//   * waves wait on the progress word independently (no workgroup barrier in
-//     the sweep) and only when their cached copy is too old;
-//   * per-XCD L2s are not coherent and L1 is never refreshed: solved x values
-//     are published with write-through (sc1) stores, drained, then the
-//     progress word is stored; consumers poll it with sc1 loads and read x
-//     with sc1 loads (guide G16, recipe R1). 2-byte storage uses an
-//     agent-scope release/acquire fence pair instead (sc1 hand-offs are only
-//     characterised for 4/8/16-byte accesses).
+//   * hand-off = the data IS the flag (guide G16, recipe R2): every solved
+//     element is published as one 8-byte {tag, value} granule with a single
+//     write-through (sc1) store into a zeroed workspace; consumers poll the
+//     granules they need with sc1 loads. No progress word, no drain, no fence
+//     on the critical path (the reference's __threadfence + volatile spin,
+//     `trsv_kernels.cuh:171-182,229-233`, would be 5 serialised memory round
+//     trips per hop here); per-XCD L2s are not coherent and L1 is never
+//     refreshed, so plain loads/stores are not an option;
+//   * per block: all waves stage the diagonal tile AND the last off-diagonal
+//     panel in LDS; wave 0 inverts the tile with each lane owning a column of
+//     the inverse in registers (2016 FMAs, no synchronisation, instead of a
+//     Gauss-Jordan sweep through shared memory with a sync per step) while
+//     the other waves already stream the far panels;
+//   * far panels (all but the last): 16-byte loads of the storage type,
+//     double-buffered in registers together with the x granules of the next
+//     panel, FMA in the arithmetic type, ONE cross-lane reduction at the end;
+//   * last panel + diagonal solve (the critical path): two 64 x 64 mat-vecs
+//     from LDS with lane = row, so no cross-lane reduction is needed after
+//     x_{b-1} arrives.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -41,17 +50,37 @@ namespace dev {
 constexpr int trsv_tile = wave_size;  // 64
 constexpr int trsv_waves = 4;         // waves per workgroup
 
+using granule_word = unsigned long long;
+
+/** 8-byte words of hand-off workspace needed per element of x. */
+template <typename St>
+constexpr int trsv_granule_words()
+{
+    return sizeof(St) == 8 ? 2 : 1;
+}
+
 
 namespace kernel {
 
 
-/** `kernel::trsv_init` (`cuda/trsv_kernels.cuh:38-42`): helper[0] = index of
- *  the last finished block (all ones = none), helper[1] = next ticket. */
-__global__ __launch_bounds__(64) void trsv_init(std::uint32_t *helper)
+/**
+ * `kernel::trsv_init` (`cuda/trsv_kernels.cuh:38-42`) plus the re-arming of the
+ * hand-off workspace: helper[0] = ~0 (stays ~0 unless a bounded spin expired,
+ * then 0xdeadbeef), helper[1] = next ticket = 0, every granule word = 0
+ * (tag 0 = not published).
+ */
+__global__ __launch_bounds__(256) void trsv_init(std::uint32_t *helper,
+                                                 granule_word *granules,
+                                                 index_type num_words)
 {
-    if (threadIdx.x == 0) {
+    const index_type tid = index_type{blockIdx.x} * blockDim.x + threadIdx.x;
+    if (tid == 0) {
         helper[0] = ~std::uint32_t{0};
         helper[1] = 0;
+    }
+    for (index_type i = tid; i < num_words;
+         i += index_type{gridDim.x} * blockDim.x) {
+        granules[i] = 0;
     }
 }
 
@@ -59,73 +88,150 @@ __global__ __launch_bounds__(64) void trsv_init(std::uint32_t *helper)
 namespace detail {
 
 
+constexpr granule_word granule_tag = granule_word{1} << 32;
+
+// Every spin is bounded: a wave that polled `trsv_spin_limit` times without
+// success (seconds; a healthy solve needs microseconds to milliseconds) writes
+// `trsv_error_word` into helper[0] and gives up; every other poller sees that
+// word within 1024 polls and gives up as well, so a protocol bug ends in a
+// wrong result that the caller can detect (helper[0] != ~0u) instead of a hung
+// GPU.
+constexpr unsigned int trsv_spin_limit = 1u << 21;
+constexpr std::uint32_t trsv_error_word = 0xdeadbeefu;
+
+/** Returns true when the caller must stop waiting. */
+__device__ __forceinline__ bool spin_expired(unsigned int &spins,
+                                             std::uint32_t *helper)
+{
+    ++spins;
+    if ((spins & 1023u) != 0) {
+        return false;
+    }
+    const std::uint32_t state = __hip_atomic_load(
+        helper, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (state == trsv_error_word) {
+        return true;
+    }
+    if (spins >= trsv_spin_limit) {
+        __hip_atomic_store(helper, trsv_error_word, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    }
+    return false;
+}
+
+/** Encoding of one storage element into 1 (<= 4 bytes) or 2 (8 bytes)
+ *  granules: low 32 bits payload, high 32 bits tag. */
 template <typename St>
-struct bits_of {
-    using type = std::conditional_t<
-        sizeof(St) == 2, unsigned short,
-        std::conditional_t<sizeof(St) == 4, unsigned int, unsigned long long>>;
+struct granule_io {
+    static constexpr int words = trsv_granule_words<St>();
+
+    __device__ __forceinline__ static void publish(granule_word *granules,
+                                                   index_type element, St value)
+    {
+        if (words == 1) {
+            unsigned int bits = 0;
+            __builtin_memcpy(&bits, &value, sizeof(St));
+            __hip_atomic_store(granules + element, granule_tag | bits,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            granule_word bits = 0;
+            __builtin_memcpy(&bits, &value, sizeof(St));
+            __hip_atomic_store(granules + 2 * element,
+                               granule_tag | (bits & 0xffffffffull),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(granules + 2 * element + 1,
+                               granule_tag | (bits >> 32), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    __device__ __forceinline__ static void load(const granule_word *granules,
+                                                index_type element,
+                                                granule_word (&raw)[words])
+    {
+#pragma unroll
+        for (int w = 0; w < words; ++w) {
+            raw[w] = __hip_atomic_load(granules + words * element + w,
+                                       __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    __device__ __forceinline__ static bool ready(
+        const granule_word (&raw)[words])
+    {
+        bool ok = true;
+#pragma unroll
+        for (int w = 0; w < words; ++w) {
+            ok = ok && (raw[w] >> 32) == 1;
+        }
+        return ok;
+    }
+
+    __device__ __forceinline__ static St decode(
+        const granule_word (&raw)[words])
+    {
+        St value;
+        if (words == 1) {
+            const unsigned int bits = static_cast<unsigned int>(raw[0]);
+            __builtin_memcpy(&value, &bits, sizeof(St));
+        } else {
+            const granule_word bits =
+                (raw[0] & 0xffffffffull) | (raw[words - 1] << 32);
+            __builtin_memcpy(&value, &bits, sizeof(St));
+        }
+        return value;
+    }
 };
-
-/** Write-through store of one storage element (visible to other XCDs after
- *  the storing wave drained its vector memory queue). */
-template <typename St>
-__device__ __forceinline__ void publish_store(St *addr, St value)
-{
-    using bits_type = typename bits_of<St>::type;
-    bits_type bits;
-    __builtin_memcpy(&bits, &value, sizeof(St));
-    __hip_atomic_store(reinterpret_cast<bits_type *>(addr), bits,
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-/** L1-bypassing load of one storage element another workgroup published. */
-template <typename St>
-__device__ __forceinline__ St consume_load(const St *addr)
-{
-    using bits_type = typename bits_of<St>::type;
-    const bits_type bits = __hip_atomic_load(
-        reinterpret_cast<const bits_type *>(addr), __ATOMIC_RELAXED,
-        __HIP_MEMORY_SCOPE_AGENT);
-    St value;
-    __builtin_memcpy(&value, &bits, sizeof(St));
-    return value;
-}
 
 
 }  // namespace detail
 
 
 /**
- * Blocked triangular solve. blockDim = (64 * Waves), grid = ceil(n / 64).
+ * Blocked triangular solve. blockDim = 64 * Waves, grid = ceil(n / 64).
  *
- * Logical (always lower-triangular) indices i' are mapped to memory indices
- * by `phys`: identity for Lower, n-1-i' for Upper. Logical block b covers
+ * Logical (always lower-triangular) indices i' map to memory indices by
+ * `phys`: identity for Lower, n-1-i' for Upper. Logical block b covers
  * i' in [64 b, 64 b + 63]; entries with i' >= n do not exist (masked).
+ * Granules are indexed by the logical element index.
+ *
+ * Vec = elements per 16-byte load in the far sweep (requires the matrix base
+ * and row stride aligned to 16 bytes, and for Upper n % Vec == 0); Vec = 1 is
+ * the fallback for any stride / alignment.
  *
  * Meaning per block as in `cuda/trsv_kernels.cuh:527-692` (lower) /
  * `:725-893` (upper): x_b = inv(T_bb) * (x_b - sum_{c<b} A_bc x_c), all in
- * ArType, x stored as StType.
+ * ArType, x stored as StType and re-read by later blocks as stored.
  */
-template <int Waves, bool Upper, bool UnitDiag, typename ArType,
+template <int Waves, bool Upper, bool UnitDiag, int Vec, typename ArType,
           typename MtxView, typename XView>
 __global__ __launch_bounds__(Waves *wave_size) void trsv(
-    MtxView mtx, XView x, std::uint32_t *helper)
+    MtxView mtx, XView x, std::uint32_t *helper, granule_word *granules)
 {
     using ar_type = decltype(mtx(0, 0) * x(0, 0));
     static_assert(std::is_same<ArType, ar_type>::value,
                   "accessor arithmetic must yield ArType");
+    using mtx_traits = view_traits<MtxView>;
     using x_traits = view_traits<XView>;
     using st_type = std::remove_cv_t<typename x_traits::storage_type>;
+    using io = detail::granule_io<st_type>;
     constexpr int B = trsv_tile;
-    constexpr int ld = B + 1;                  // LDS leading dimension
-    constexpr int rows_per_wave = B / Waves;   // rows each wave sweeps
-    constexpr bool fenced = sizeof(st_type) == 2;
+    constexpr int ld = B + 1;                 // LDS leading dimension
+    constexpr int RW = B / Waves;             // rows per wave in the sweep
+    constexpr int LPR = B / Vec;              // lanes sharing one tile row
+    constexpr int NI = RW / Vec;              // load instructions per panel
+    static_assert(RW % Vec == 0 && B % Vec == 0, "bad Vec");
 
-    // tile: first the diagonal tile row-major (tile[r*ld + c]), later its
-    // inverse column-major (tile[c*ld + r])
+    // tile: the diagonal tile row-major (tile[r*ld + c]), later its inverse
+    // column-major (tile[c*ld + r]); panel: the last off-diagonal panel
+    // column-major (panel[c*ld + r]) so that lane = row reads are conflict-free
     __shared__ ar_type tile[B * ld];
+    __shared__ ar_type panel[B * ld];
     __shared__ ar_type correction[B];
-    __shared__ ar_type rhs[B];
+    __shared__ ar_type vec_a[B];
+    __shared__ ar_type vec_b[B];
     __shared__ std::int32_t shared_block;
 
     const int lane = lane_id();
@@ -146,10 +252,22 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     const auto phys = [n](index_type logical) {
         return Upper ? n - 1 - logical : logical;
     };
+    const st_type *a_data = mtx_traits::data(mtx);
+    const index_type lda = mtx_traits::stride(mtx);
     st_type *x_data = x_traits::data(x);
     const index_type x_inc = x_traits::stride(x);
 
-    // ---- diagonal tile -> LDS (coalesced: a wave reads one row) ----------
+    // this block's right-hand side values (lane = row), never written by
+    // another workgroup: plain load, issued early
+    const index_type own_row = base + lane;
+    const bool own_valid = own_row < n;
+    st_type *own_addr = x_data + phys(own_valid ? own_row : n - 1) * x_inc;
+    ar_type own_rhs{};
+    if (wave == 0 && own_valid) {
+        own_rhs = static_cast<ar_type>(*own_addr);
+    }
+
+    // ---- diagonal tile and last panel -> LDS (a wave reads one row) -------
     for (int r = wave; r < B; r += Waves) {
         const index_type gr = base + r;
         const index_type gc = base + lane;
@@ -161,6 +279,13 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
             value = mtx(phys(gr), phys(gc));
         }
         tile[r * ld + lane] = value;
+        if (block > 0) {
+            ar_type off{};
+            if (gr < n) {
+                off = mtx(phys(gr), phys(base - B + lane));
+            }
+            panel[lane * ld + r] = off;
+        }
     }
     __syncthreads();
 
@@ -181,93 +306,158 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
             column[i] = value;
         }
         // all reads of T are done (same wave, program order): overwrite with
-        // the inverse, column-major so that lane = row reads are conflict-free
+        // the inverse, column-major
 #pragma unroll
         for (int i = 0; i < B; ++i) {
             tile[lane * ld + i] = column[i];
         }
     }
 
-    // ---- off-diagonal sweep: correction = sum_{c<block} A[block][c] x_c ---
-    ar_type partial[rows_per_wave];
+    // ---- far sweep: correction = sum_{c < block-1} A[block][c] x_c --------
+    // Instruction k of a wave covers tile rows wave*RW + k*Vec + lane/LPR and
+    // Vec consecutive (logical) columns starting at (lane % LPR) * Vec.
+    const index_type far_end = block - 1;  // panels [0, far_end)
+    const int row_in_inst = lane / LPR;
+    const int col_group = lane % LPR;
+    struct stage {
+        st_type a[NI][Vec];
+        granule_word xraw[Vec][io::words];
+    };
+    const st_type *row_ptr[NI];
 #pragma unroll
-    for (int l = 0; l < rows_per_wave; ++l) {
-        partial[l] = ar_type{};
+    for (int k = 0; k < NI; ++k) {
+        const index_type gr = base + wave * RW + k * Vec + row_in_inst;
+        row_ptr[k] = a_data + phys(gr < n ? gr : n - 1) * lda;
     }
-    // rows of this wave: wave, wave + Waves, ... ; clamp masked rows for
-    // loading and zero their contribution
-    std::int32_t known_done = -1;
-    for (index_type cb = 0; cb < block; ++cb) {
-        if (known_done < cb) {
-            // one relaxed sc1 poll per wave; uniform result
-            std::int32_t seen;
-            do {
-                seen = static_cast<std::int32_t>(__hip_atomic_load(
-                    helper, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                seen = __builtin_amdgcn_readfirstlane(seen);
-                if (seen < cb) {
-                    __builtin_amdgcn_s_sleep(1);
+    const auto issue = [&](index_type cb, stage &s) {
+        const index_type first_col = cb * B + col_group * Vec;  // logical
+        // lowest memory column of the group (columns descend for Upper)
+        const index_type mem_col =
+            Upper ? n - 1 - (first_col + Vec - 1) : first_col;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            if (Vec > 1) {
+                const auto v = load_packed<(Vec > 1 ? Vec : 2), true>(
+                    row_ptr[k] + mem_col);
+#pragma unroll
+                for (int e = 0; e < Vec; ++e) {
+                    s.a[k][e] = v[e];
                 }
-            } while (seen < cb);
-            known_done = seen;
-            if (fenced) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             } else {
-                // keeps the compiler from hoisting the x load over the poll
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                s.a[k][0] = row_ptr[k][mem_col];
             }
         }
-        const index_type gc = cb * B + lane;
-        const ar_type x_value = static_cast<ar_type>(
-            detail::consume_load(x_data + phys(gc) * x_inc));
 #pragma unroll
-        for (int l = 0; l < rows_per_wave; ++l) {
-            const index_type gr = base + wave + l * Waves;
-            if (gr < n) {
-                partial[l] += x_value * mtx(phys(gr), phys(gc));
+        for (int e = 0; e < Vec; ++e) {
+            io::load(granules, first_col + e, s.xraw[e]);
+        }
+    };
+    ar_type acc[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        acc[k] = ar_type{};
+    }
+    unsigned int spins = 0;
+    const auto consume = [&](index_type cb, stage &s) {
+        const index_type first_col = cb * B + col_group * Vec;
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int e = 0; e < Vec; ++e) {
+                ok = ok && io::ready(s.xraw[e]);
             }
+            if (__all(ok) || detail::spin_expired(spins, helper)) {
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int e = 0; e < Vec; ++e) {
+                io::load(granules, first_col + e, s.xraw[e]);
+            }
+        }
+        ar_type xv[Vec];
+#pragma unroll
+        for (int e = 0; e < Vec; ++e) {
+            xv[e] = static_cast<ar_type>(io::decode(s.xraw[e]));
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+#pragma unroll
+            for (int e = 0; e < Vec; ++e) {
+                // memory element e of an Upper group is logical column
+                // Vec-1-e of the group
+                acc[k] += static_cast<ar_type>(s.a[k][e]) *
+                          xv[Upper ? Vec - 1 - e : e];
+            }
+        }
+    };
+    if (far_end > 0) {
+        stage even, odd;
+        issue(0, even);
+        index_type cb = 0;
+        for (; cb + 1 < far_end; cb += 2) {
+            issue(cb + 1, odd);
+            consume(cb, even);
+            if (cb + 2 < far_end) {
+                issue(cb + 2, even);
+            }
+            consume(cb + 1, odd);
+        }
+        if (cb < far_end) {
+            consume(cb, even);
         }
     }
 #pragma unroll
-    for (int l = 0; l < rows_per_wave; ++l) {
-        const ar_type total = group_all_reduce(
-            partial[l], [](ar_type a, ar_type b) { return a + b; });
-        if (lane == 0) {
-            correction[wave + l * Waves] = total;
+    for (int k = 0; k < NI; ++k) {
+        const ar_type total = group_all_reduce<LPR>(
+            acc[k], [](ar_type a, ar_type b) { return a + b; });
+        if (col_group == 0) {
+            const int r = wave * RW + k * Vec + row_in_inst;
+            correction[r] = (base + r < n) ? total : ar_type{};
         }
     }
     __syncthreads();
 
-    // ---- solve the diagonal system with the inverse (lane = row) ----------
+    // ---- critical path: last panel, then the diagonal solve (lane = row) --
     if (wave == 0) {
-        const index_type gr = base + lane;
-        const bool valid = gr < n;
-        st_type *x_addr = x_data + phys(valid ? gr : n - 1) * x_inc;
-        ar_type local_rhs{};
-        if (valid) {
-            local_rhs = static_cast<ar_type>(*x_addr) - correction[lane];
+        ar_type rhs = own_rhs - correction[lane];
+        if (block > 0) {
+            granule_word raw[io::words];
+            const index_type prev = base - B + lane;  // always < n
+            io::load(granules, prev, raw);
+            while (!__all(io::ready(raw)) &&
+                   !detail::spin_expired(spins, helper)) {
+                __builtin_amdgcn_s_sleep(1);
+                io::load(granules, prev, raw);
+            }
+            vec_a[lane] = static_cast<ar_type>(io::decode(raw));
+            ar_type sum[4] = {};
+#pragma unroll
+            for (int c = 0; c < B; c += 4) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    sum[s] += panel[(c + s) * ld + lane] * vec_a[c + s];
+                }
+            }
+            rhs -= (sum[0] + sum[1]) + (sum[2] + sum[3]);
         }
-        rhs[lane] = local_rhs;
+        if (!own_valid) {
+            rhs = ar_type{};
+        }
+        vec_b[lane] = rhs;
         ar_type sum[4] = {};
 #pragma unroll
         for (int c = 0; c < B; c += 4) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                sum[s] += tile[(c + s) * ld + lane] * rhs[c + s];
+                sum[s] += tile[(c + s) * ld + lane] * vec_b[c + s];
             }
         }
-        const ar_type solution = (sum[0] + sum[1]) + (sum[2] + sum[3]);
-        if (valid) {
-            detail::publish_store(x_addr, static_cast<st_type>(solution));
-        }
-        drain_vmem();
-        if (fenced) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            drain_vmem();
-        }
-        if (lane == 0) {
-            __hip_atomic_store(helper, static_cast<std::uint32_t>(block),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const st_type solution = static_cast<st_type>(
+            (sum[0] + sum[1]) + (sum[2] + sum[3]));
+        if (own_valid) {
+            io::publish(granules, own_row, solution);  // hand-off first
+            *own_addr = solution;                       // the user's vector
         }
     }
 }
@@ -276,36 +466,61 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
 }  // namespace kernel
 
 
+/** Bytes of hand-off workspace `launch_trsv` needs for an n-element solve. */
+template <typename St>
+constexpr std::size_t trsv_workspace_bytes(index_type n)
+{
+    return static_cast<std::size_t>(n) * trsv_granule_words<St>() *
+           sizeof(granule_word);
+}
+
+
 template <typename ArType, typename MtxView, typename XView>
 hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
                        const XView &x, std::uint32_t *helper,
-                       hipStream_t stream)
+                       granule_word *granules, hipStream_t stream)
 {
+    using mtx_traits = view_traits<MtxView>;
+    using st_type =
+        std::remove_cv_t<typename view_traits<XView>::storage_type>;
     const index_type n = mtx.length(0);
     if (n <= 0) {
         return hipSuccess;
     }
     constexpr int waves = trsv_waves;
+    constexpr int vec16 = 16 / sizeof(st_type);
     const dim3 grid(static_cast<unsigned>(ceildiv(n, trsv_tile)), 1, 1);
     const dim3 block(waves * wave_size, 1, 1);
-    kernel::trsv_init<<<1, 64, 0, stream>>>(helper);
+    const index_type num_words = n * trsv_granule_words<st_type>();
+    const unsigned init_blocks =
+        static_cast<unsigned>(std::min<index_type>(ceildiv(num_words, 256), 512));
+    kernel::trsv_init<<<init_blocks, 256, 0, stream>>>(helper, granules,
+                                                       num_words);
+    const bool vec_ok = is_aligned(mtx_traits::data(mtx), 16) &&
+                        mtx_traits::stride(mtx) % vec16 == 0 &&
+                        (!upper || n % vec16 == 0);
+#define ACCBLAS_TRSV_LAUNCH(_upper, _unit)                                     \
+    if (vec_ok) {                                                              \
+        kernel::trsv<waves, _upper, _unit, vec16, ArType>                      \
+            <<<grid, block, 0, stream>>>(mtx, x, helper, granules);            \
+    } else {                                                                   \
+        kernel::trsv<waves, _upper, _unit, 1, ArType>                          \
+            <<<grid, block, 0, stream>>>(mtx, x, helper, granules);            \
+    }
     if (upper) {
         if (unit_diag) {
-            kernel::trsv<waves, true, true, ArType>
-                <<<grid, block, 0, stream>>>(mtx, x, helper);
+            ACCBLAS_TRSV_LAUNCH(true, true)
         } else {
-            kernel::trsv<waves, true, false, ArType>
-                <<<grid, block, 0, stream>>>(mtx, x, helper);
+            ACCBLAS_TRSV_LAUNCH(true, false)
         }
     } else {
         if (unit_diag) {
-            kernel::trsv<waves, false, true, ArType>
-                <<<grid, block, 0, stream>>>(mtx, x, helper);
+            ACCBLAS_TRSV_LAUNCH(false, true)
         } else {
-            kernel::trsv<waves, false, false, ArType>
-                <<<grid, block, 0, stream>>>(mtx, x, helper);
+            ACCBLAS_TRSV_LAUNCH(false, false)
         }
     }
+#undef ACCBLAS_TRSV_LAUNCH
     return hipGetLastError();
 }
 
