@@ -6,8 +6,7 @@
 #include <mutex>
 #include <utility>
 
-#include "accblas_internal.hpp"
-#include "trsv_kernels.hpp"
+#include "accblas_trsv_common.hpp"
 
 
 namespace {
@@ -23,8 +22,11 @@ struct workspace_entry {
     std::size_t bytes{0};
 };
 
-int get_workspace(hipStream_t stream, std::size_t bytes,
-                  accblas::dev::granule_word **out)
+}  // namespace
+
+
+int accblas::trsv_get_workspace(hipStream_t stream, std::size_t bytes,
+                                accblas::dev::granule_word **out)
 {
     static std::mutex guard;
     static std::map<std::pair<int, hipStream_t>, workspace_entry> cache;
@@ -58,6 +60,9 @@ int get_workspace(hipStream_t stream, std::size_t bytes,
     *out = static_cast<accblas::dev::granule_word *>(entry.ptr);
     return ACCBLAS_OK;
 }
+
+
+namespace {
 
 
 
@@ -119,7 +124,7 @@ int accblas_trsv(accblas_dtype vt, accblas_uplo uplo, accblas_diag diag,
                                             {n, 1}, incx};
         granule_word *granules = nullptr;
         const int ws_status =
-            get_workspace(accblas::as_stream(stream),
+            accblas::trsv_get_workspace(accblas::as_stream(stream),
                           trsv_workspace_bytes<value_type>(n), &granules);
         if (ws_status != ACCBLAS_OK) {
             return ws_status;
@@ -141,39 +146,16 @@ int accblas_acc_trsv(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
     if (status != ACCBLAS_OK) {
         return status;
     }
-    return accblas::dispatch_arithmetic(ar, [&](auto ar_tag) {
-        using ar_type = typename decltype(ar_tag)::type;
-        return accblas::dispatch_type(st, [&](auto st_tag) {
-            using st_type = typename decltype(st_tag)::type;
-            // Accessor setup, as cuda/trsv_kernels.cuh:923-933
-            constexpr std::size_t dimensionality{2};
-            using accessor =
-                gko::acc::reduced_row_major<dimensionality, ar_type, st_type>;
-            using range = gko::acc::range<accessor>;
-            using c_range =
-                gko::acc::range<typename accessor::const_accessor>;
-            using size_array = std::array<gko::acc::size_type, 2>;
-            using stride_array = std::array<gko::acc::size_type, 1>;
-            const auto m_acc =
-                c_range(size_array{{n, n}}, static_cast<const st_type *>(A),
-                        stride_array{{lda}});
-            const auto x_acc = range(size_array{{n, 1}},
-                                     static_cast<st_type *>(x),
-                                     stride_array{{incx}});
-            accblas::dev::granule_word *granules = nullptr;
-            const int ws_status = get_workspace(
-                accblas::as_stream(stream),
-                accblas::dev::trsv_workspace_bytes<st_type>(n), &granules);
-            if (ws_status != ACCBLAS_OK) {
-                return ws_status;
-            }
-            return accblas::check_hip(
-                accblas::dev::launch_trsv<ar_type>(
-                    uplo == ACCBLAS_UPPER, diag == ACCBLAS_UNIT, m_acc, x_acc,
-                    helper, granules, accblas::as_stream(stream)),
-                "acc_trsv launch");
-        });
-    });
+    if (ar == ACCBLAS_F32) {
+        return accblas::acc_trsv_f32(st, uplo, diag, n, A, lda, x, incx,
+                                     helper, stream);
+    }
+    if (ar == ACCBLAS_F64) {
+        return accblas::acc_trsv_f64(st, uplo, diag, n, A, lda, x, incx,
+                                     helper, stream);
+    }
+    return accblas::set_error(ACCBLAS_ERR_UNSUPPORTED_TYPES,
+                              "arithmetic type must be f32 or f64");
 }
 
 

@@ -69,9 +69,8 @@ namespace kernel {
  * then 0xdeadbeef), helper[1] = next ticket = 0, every granule word = 0
  * (tag 0 = not published).
  */
-__global__ __launch_bounds__(256) void trsv_init(std::uint32_t *helper,
-                                                 granule_word *granules,
-                                                 index_type num_words)
+static __global__ __launch_bounds__(256) void trsv_init(
+    std::uint32_t *helper, granule_word *granules, index_type num_words)
 {
     const index_type tid = index_type{blockIdx.x} * blockDim.x + threadIdx.x;
     if (tid == 0) {

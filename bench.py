@@ -44,6 +44,8 @@ def parse_args():
     p.add_argument("--st", default="f32", choices=["f16", "f32", "f64"])
     p.add_argument("--ar", default="f64", choices=["f32", "f64"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-other-configs", action="store_true",
+                   help="skip the untimed measurements of the other BASELINE configs")
     return p.parse_args()
 
 
@@ -75,6 +77,140 @@ def cpu_baseline(oracle, ar, A_rows, lda, x, res_rows, threads):
     one_rows = max(rows // 8, 1)
     t_one = run(0, one_rows, 1, res_rows.copy())
     return (2.0 * rows * cols / t_all / 1e9, 2.0 * one_rows * cols / t_one / 1e9, res_all)
+
+
+def event_time_us(accblas, torch, fn, stream, reps=5):
+    """min-of-reps HIP-event time of fn() in microseconds."""
+    fn()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(reps):
+        a, b = accblas.Event(), accblas.Event()
+        a.record(stream)
+        fn()
+        b.record(stream)
+        b.synchronize()
+        best = min(best, a.elapsed_ms(b) * 1e3)
+    return best
+
+
+def other_configs(accblas, torch, dev, stream, dist, world, rank):
+    """The remaining BASELINE.json configurations, measured outside the timed
+    region of the headline metric (min-of-5 event times). Every rank runs this
+    (the sharded dot needs all of them); rank 0 reports."""
+    F16, F32, F64 = accblas.F16, accblas.F32, accblas.F64
+    out = {}
+
+    def uniform(count, dtype, scale=1.0, seed=1):
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        return torch.rand(count, dtype=dtype, device=dev, generator=g) \
+            .mul_(2 * scale).sub_(scale)
+
+    # -- configs[1]: GEMV 16384^2 fp64/fp64, plain pointers vs accessor
+    n = 16384
+    A, x = uniform(n * n, torch.float64, seed=11), uniform(n, torch.float64, seed=12)
+    r0 = uniform(n, torch.float64, seed=13)
+    r_plain, r_acc = r0.clone(), r0.clone()
+    accblas.gemv(F64, n, n, 1.0, A, n, x, 1, 1.0, r_plain, 1, stream)
+    accblas.acc_gemv(F64, F64, n, n, 1.0, A, n, x, 1, 1.0, r_acc, 1, stream)
+    torch.cuda.synchronize()
+    identical = bool(torch.equal(r_plain, r_acc))
+    t_plain = event_time_us(accblas, torch, lambda: accblas.gemv(
+        F64, n, n, 1.0, A, n, x, 1, 1.0, r_plain, 1, stream), stream)
+    t_acc = event_time_us(accblas, torch, lambda: accblas.acc_gemv(
+        F64, F64, n, n, 1.0, A, n, x, 1, 1.0, r_acc, 1, stream), stream)
+    byts = 8.0 * (n * n + 3 * n)
+    out["gemv_16384_fp64_fp64"] = {
+        "plain_us": t_plain, "acc_us": t_acc, "plain_GBs": byts / t_plain / 1e3,
+        "acc_GBs": byts / t_acc / 1e3, "acc_frac_of_8TBs": byts / t_acc / 1e3 / HBM_PEAK_GBS,
+        "plain_equals_accessor_bitwise": identical}
+    del A, x, r0, r_plain, r_acc
+
+    # -- configs[3]: dot n = 2^28, storage fp16, arithmetic fp32, chunked over the
+    # ranks, one all-reduce of a single fp32 element (SURVEY.md §8e E2)
+    from accblas import multi_gpu
+    n_total = 1 << 28
+    lo, hi = multi_gpu.shard_bounds(n_total, world, rank)
+    count = hi - lo
+    x64 = uniform(count, torch.float64, seed=100 + rank)
+    y64 = uniform(count, torch.float64, seed=200 + rank)
+    xh = torch.empty(count, dtype=torch.float16, device=dev)
+    yh = torch.empty(count, dtype=torch.float16, device=dev)
+    accblas.convert(F16, xh, F64, x64, count, stream)
+    accblas.convert(F16, yh, F64, y64, count, stream)
+    handle = accblas.Handle()
+    partial = torch.zeros(1, dtype=torch.float32, device=dev)
+    ref = torch.zeros(1, dtype=torch.float64, device=dev)
+    accblas.dot(handle, F64, count, x64, 1, y64, 1, ref, stream)  # fp64 reference
+
+    def local_dot(_lo, _hi):
+        accblas.acc_dot(handle, F32, F16, F32, count, xh, 1, yh, 1, partial, stream)
+        return partial
+
+    t_kernel = event_time_us(accblas, torch, lambda: local_dot(lo, hi), stream)
+    reps = 20
+    multi_gpu.sharded_dot(local_dot, n_total, dist=dist)  # warm-up incl. RCCL
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        total = multi_gpu.sharded_dot(local_dot, n_total, dist=dist)
+    torch.cuda.synchronize()
+    t_e2e = (time.perf_counter() - t0) / reps * 1e6
+    got = float(total.item())
+    if dist is not None:
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        t = torch.tensor([t_kernel, t_e2e], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_kernel, t_e2e = float(t[0]), float(t[1])
+    want = float(ref.item())
+    out["dot_2p28_fp16_fp32"] = {
+        "elements_per_gpu": count, "kernel_us": t_kernel,
+        "kernel_GBs_per_gpu": 4.0 * count / t_kernel / 1e3,
+        "end_to_end_us_incl_allreduce": t_e2e,
+        "aggregate_GBs_end_to_end": 4.0 * n_total / t_e2e / 1e3,
+        "collective": "all_reduce(sum) of 1 fp32 element" if world > 1 else "none",
+        "rel_err_vs_fp64": abs(got - want) / abs(want)}
+    handle.close()
+    del x64, y64, xh, yh
+
+    # -- configs[4]: TRSV n = 65536, lower, unit diagonal, storage fp32,
+    # arithmetic fp64; does not shard (replicas only), so rank 0 only
+    if rank == 0:
+        n = 65536
+        L = uniform(n * n, torch.float32, scale=1.0 / n ** 0.5, seed=31)
+        b = uniform(n, torch.float32, seed=32)
+        xs = b.clone()
+        helper = torch.zeros(2, dtype=torch.int32, device=dev)
+
+        def solve():
+            xs.copy_(b)
+            accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, L, n, xs, 1, helper,
+                             stream)
+        t_solve = event_time_us(accblas, torch, solve, stream, reps=3)
+        t_copy = event_time_us(accblas, torch, lambda: xs.copy_(b), stream, reps=3)
+        solve()
+        torch.cuda.synchronize()
+        # residual of 256 sampled rows in fp64: (L x)_i + x_i - b_i
+        rows = torch.randint(0, n, (256,), device=dev)
+        Lr = L.view(n, n)[rows].double()
+        cols = torch.arange(n, device=dev)
+        Lr = torch.where(cols[None, :] < rows[:, None], Lr, torch.zeros_like(Lr))
+        resid = Lr @ xs.double() + xs.double()[rows] - b.double()[rows]
+        byts = 4.0 * (n * (n - 1) / 2 + 2 * n)
+        t_trsv = t_solve - t_copy
+        out["trsv_65536_lower_unit_fp32_fp64"] = {
+            "us": t_trsv, "GBs": byts / t_trsv / 1e3,
+            "frac_of_8TBs": byts / t_trsv / 1e3 / HBM_PEAK_GBS,
+            "us_per_64row_hop": t_trsv / (n / 64),
+            "sampled_residual_rel": float(resid.abs().sum() / b.double()[rows].abs().sum()),
+            "helper_word": int(helper[0].item()) & 0xffffffff}
+        del L
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -170,6 +306,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
+    sample_rows = min(rows, 4096)
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    A_sample = A_st[: sample_rows * lda].cpu().numpy() if want_cpu else None
+    del A_st
+    torch.cuda.empty_cache()
+    extras = None
+    if not args.no_other_configs and n == 32768:
+        extras = other_configs(accblas, torch, dev, stream, dist, world, rank)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -229,8 +374,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         # the GPU box gives one-GPU jobs a share of 16 host cores
         threads = min(len(os.sched_getaffinity(0)), 16)
-        sample_rows = min(rows, 4096)
-        A_rows = A_st[: sample_rows * lda].cpu().numpy()
+        A_rows = A_sample
         x_h = x_st.cpu().numpy()
         res_rows = res0_st[:sample_rows].cpu().numpy()
         g_all, g_one, res_cpu = cpu_baseline(oracle, ar, A_rows, lda, x_h, res_rows, threads)
@@ -253,6 +397,8 @@ def main():
             (time.perf_counter() - t0) / 20 * 1e6
         out["parity_sample_rel_err_vs_oracle"] = oracle.rel_error(
             res_cpu.astype(np.float64), got_h[:sample_rows].astype(np.float64))
+    if extras is not None:
+        out["other_configs"] = extras
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
