@@ -33,8 +33,9 @@
 //     double-buffered in registers together with the x granules of the next
 //     panel, FMA in the arithmetic type, ONE cross-lane reduction at the end;
 //   * last panel + diagonal solve (the critical path): two 64 x 64 mat-vecs
-//     from LDS with lane = row, so no cross-lane reduction is needed after
-//     x_{b-1} arrives.
+//     from LDS with lane = row (no cross-lane reduction after x_{b-1}
+//     arrives), columns split over the waves, vector entries broadcast with
+//     v_readlane, per-wave partials combined through LDS.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -58,6 +59,24 @@ constexpr int trsv_granule_words()
 {
     return sizeof(St) == 8 ? 2 : 1;
 }
+
+
+// Diagnostic builds only (tools/tune_trsv.hip defines ACCBLAS_TRSV_DIAG): every
+// block records 100 MHz wall-clock stamps of its phases into a buffer that no
+// other code reads. The library is never built with it.
+#ifdef ACCBLAS_TRSV_DIAG
+__device__ unsigned long long *trsv_diag_buffer;
+#define ACCBLAS_TRSV_STAMP(_block, _slot)                                  \
+    do {                                                                   \
+        if (lane_id() == 0 && trsv_diag_buffer != nullptr) {               \
+            trsv_diag_buffer[(_block)*8 + (_slot)] = wall_clock64();       \
+        }                                                                  \
+    } while (false)
+#else
+#define ACCBLAS_TRSV_STAMP(_block, _slot) \
+    do {                                  \
+    } while (false)
+#endif
 
 
 namespace kernel {
@@ -117,6 +136,29 @@ __device__ __forceinline__ bool spin_expired(unsigned int &spins,
         return true;
     }
     return false;
+}
+
+/** Value of `value` in lane `src_lane` (wave-uniform index), broadcast to all
+ *  lanes through SGPRs (v_readlane_b32; two for 8-byte types). */
+template <typename T>
+__device__ __forceinline__ T read_lane(T value, int src_lane)
+{
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4/8-byte values only");
+    if (sizeof(T) == 4) {
+        int bits;
+        __builtin_memcpy(&bits, &value, 4);
+        bits = __builtin_amdgcn_readlane(bits, src_lane);
+        T out;
+        __builtin_memcpy(&out, &bits, 4);
+        return out;
+    }
+    int halves[2];
+    __builtin_memcpy(halves, &value, 8);
+    halves[0] = __builtin_amdgcn_readlane(halves[0], src_lane);
+    halves[1] = __builtin_amdgcn_readlane(halves[1], src_lane);
+    T out;
+    __builtin_memcpy(&out, halves, 8);
+    return out;
 }
 
 /** Encoding of one storage element into 1 (<= 4 bytes) or 2 (8 bytes)
@@ -229,8 +271,8 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     __shared__ ar_type tile[B * ld];
     __shared__ ar_type panel[B * ld];
     __shared__ ar_type correction[B];
-    __shared__ ar_type vec_a[B];
-    __shared__ ar_type vec_b[B];
+    __shared__ ar_type partial_a[Waves * B];
+    __shared__ ar_type partial_b[Waves * B];
     __shared__ std::int32_t shared_block;
 
     const int lane = lane_id();
@@ -248,6 +290,9 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     if (base >= n) {
         return;
     }
+    if (wave == 0) {
+        ACCBLAS_TRSV_STAMP(block, 0);  // ticket drawn
+    }
     const auto phys = [n](index_type logical) {
         return Upper ? n - 1 - logical : logical;
     };
@@ -262,7 +307,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     const bool own_valid = own_row < n;
     st_type *own_addr = x_data + phys(own_valid ? own_row : n - 1) * x_inc;
     ar_type own_rhs{};
-    if (wave == 0 && own_valid) {
+    if (own_valid) {
         own_rhs = static_cast<ar_type>(*own_addr);
     }
 
@@ -310,6 +355,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
         for (int i = 0; i < B; ++i) {
             tile[lane * ld + i] = column[i];
         }
+        ACCBLAS_TRSV_STAMP(block, 1);  // inverse ready
     }
 
     // ---- far sweep: correction = sum_{c < block-1} A[block][c] x_c --------
@@ -415,49 +461,81 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
             correction[r] = (base + r < n) ? total : ar_type{};
         }
     }
+    if (wave == 0) {
+        ACCBLAS_TRSV_STAMP(block, 2);  // wave 0 finished its far sweep share
+    }
     __syncthreads();
 
-    // ---- critical path: last panel, then the diagonal solve (lane = row) --
+    // ---- critical path: last panel, then the diagonal solve ---------------
+    // Both are 64 x 64 mat-vecs from LDS with lane = row. The columns are
+    // split over the waves (CW each); a wave broadcasts its column's vector
+    // entry from the lane that holds it with v_readlane (no LDS round trip),
+    // and the per-wave partial results are combined through LDS in a fixed
+    // order. One wave alone needs ~2.4 us for the two fp64 mat-vecs; four
+    // waves need about a quarter of that plus two barriers.
+    constexpr int CW = B / Waves;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     if (wave == 0) {
-        ar_type rhs = own_rhs - correction[lane];
-        if (block > 0) {
-            granule_word raw[io::words];
-            const index_type prev = base - B + lane;  // always < n
+        ACCBLAS_TRSV_STAMP(block, 3);  // all waves finished the far sweep
+    }
+    ar_type rhs = own_rhs - correction[lane];
+    if (block > 0) {
+        // this wave's columns of the last panel: logical columns
+        // base - B + wave*CW + j, j < CW; lane l polls column (l % CW)
+        granule_word raw[io::words];
+        const index_type prev = base - B + wave_u * CW + (lane % CW);
+        io::load(granules, prev, raw);
+        while (!__all(io::ready(raw)) &&
+               !detail::spin_expired(spins, helper)) {
+            __builtin_amdgcn_s_sleep(1);
             io::load(granules, prev, raw);
-            while (!__all(io::ready(raw)) &&
-                   !detail::spin_expired(spins, helper)) {
-                __builtin_amdgcn_s_sleep(1);
-                io::load(granules, prev, raw);
-            }
-            vec_a[lane] = static_cast<ar_type>(io::decode(raw));
-            ar_type sum[4] = {};
-#pragma unroll
-            for (int c = 0; c < B; c += 4) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    sum[s] += panel[(c + s) * ld + lane] * vec_a[c + s];
-                }
-            }
-            rhs -= (sum[0] + sum[1]) + (sum[2] + sum[3]);
         }
-        if (!own_valid) {
-            rhs = ar_type{};
+        if (wave == 0) {
+            ACCBLAS_TRSV_STAMP(block, 4);  // x_{b-1} observed
         }
-        vec_b[lane] = rhs;
-        ar_type sum[4] = {};
+        const ar_type x_prev = static_cast<ar_type>(io::decode(raw));
+        ar_type part[2] = {};
 #pragma unroll
-        for (int c = 0; c < B; c += 4) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                sum[s] += tile[(c + s) * ld + lane] * vec_b[c + s];
-            }
+        for (int j = 0; j < CW; ++j) {
+            part[j & 1] += panel[(wave_u * CW + j) * ld + lane] *
+                           detail::read_lane(x_prev, j);
         }
-        const st_type solution = static_cast<st_type>(
-            (sum[0] + sum[1]) + (sum[2] + sum[3]));
+        partial_a[wave_u * B + lane] = part[0] + part[1];
+        __syncthreads();
+        ar_type sum = partial_a[lane];
+#pragma unroll
+        for (int w = 1; w < Waves; ++w) {
+            sum += partial_a[w * B + lane];
+        }
+        rhs -= sum;
+    }
+    if (!own_valid) {
+        rhs = ar_type{};
+    }
+    {
+        // every wave holds the full right-hand side (lane = row); row
+        // wave*CW + j of it is column wave*CW + j of the inverse's mat-vec
+        ar_type part[2] = {};
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+            part[j & 1] += tile[(wave_u * CW + j) * ld + lane] *
+                           detail::read_lane(rhs, wave_u * CW + j);
+        }
+        partial_b[wave_u * B + lane] = part[0] + part[1];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        ar_type sum = partial_b[lane];
+#pragma unroll
+        for (int w = 1; w < Waves; ++w) {
+            sum += partial_b[w * B + lane];
+        }
+        const st_type solution = static_cast<st_type>(sum);
         if (own_valid) {
             io::publish(granules, own_row, solution);  // hand-off first
             *own_addr = solution;                       // the user's vector
         }
+        ACCBLAS_TRSV_STAMP(block, 5);  // published
     }
 }
 

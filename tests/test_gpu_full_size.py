@@ -1,0 +1,186 @@
+"""GPU tests at BASELINE.json's full sizes, through size-independent properties
+(the CPU oracle cannot finish these sizes in seconds): linearity and
+slice-consistency for GEMV, chunk additivity for dot, residuals and
+uplo-symmetry for TRSV, plus oracle checks on sampled rows. Run with -m gpu."""
+import numpy as np
+import pytest
+
+import oracle_lib as oracle
+from oracle_lib import F16, F32, F64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import accblas
+    accblas.load()
+    assert torch.cuda.is_available()
+    return torch, accblas
+
+
+def uniform(torch, count, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return torch.rand(count, dtype=dtype, device="cuda", generator=g).mul_(2 * scale).sub_(scale)
+
+
+def rel_l1(torch, want, got):
+    return float((want.double() - got.double()).abs().sum() / want.double().abs().sum())
+
+
+def test_config_c3_gemv_32768_fp32_storage_fp64_arithmetic(gpu):
+    """GEMV 32768^2, St=fp32, Ar=fp64: (1) sampled rows match the semantic oracle,
+    (2) linearity A(x1+x2) = A x1 + A x2 (beta = 0), (3) a row slice computed alone
+    equals the same rows of the full product bit for bit (row blocks are independent:
+    this is what the multi-GPU sharding relies on), (4) error vs the fp64 kernel on the
+    unrounded master ~4e-8 (gate 1e-7, SURVEY.md §8d D4 check 2)."""
+    torch, accblas = gpu
+    n = 32768
+    A64 = uniform(torch, n * n, torch.float64, 1)
+    x64 = uniform(torch, n, torch.float64, 2)
+    r64 = uniform(torch, n, torch.float64, 3)
+    A, x, r0 = A64.float(), x64.float(), r64.float()
+    ref = r64.clone()
+    accblas.gemv(F64, n, n, 1.0, A64, n, x64, 1, 1.0, ref, 1)
+    res = r0.clone()
+    accblas.acc_gemv(F64, F32, n, n, 1.0, A, n, x, 1, 1.0, res, 1)
+    torch.cuda.synchronize()
+    err = oracle.rel_error(ref.cpu().numpy(), res.cpu().numpy().astype(np.float64))
+    assert 1e-8 < err <= 1e-7, err
+    del A64
+
+    # (1) oracle on 8 sampled rows
+    rows = [0, 1, 4095, 12345, 20000, 32766, 32767, 777]
+    A_rows = np.concatenate([A[r * n:(r + 1) * n].cpu().numpy() for r in rows])
+    want = oracle.exact_gemv(F64, len(rows), n, 1.0, A_rows, n, x.cpu().numpy(), 1, 1.0,
+                             r0.cpu().numpy()[rows], 1)
+    got = res.cpu().numpy()[rows]
+    assert oracle.rel_error(want.astype(np.float64), got.astype(np.float64)) <= 1e-7
+
+    # (2) linearity with beta = 0 (results narrowed to fp32: tolerance 2 ulp(fp32))
+    x2 = uniform(torch, n, torch.float32, 4)
+    y1, y2, y12 = (torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(3))
+    accblas.acc_gemv(F64, F32, n, n, 1.0, A, n, x, 1, 0.0, y1, 1)
+    accblas.acc_gemv(F64, F32, n, n, 1.0, A, n, x2, 1, 0.0, y2, 1)
+    xs = (x.double() + x2.double()).float()  # one rounding; compare against that input
+    accblas.acc_gemv(F64, F32, n, n, 1.0, A, n, xs, 1, 0.0, y12, 1)
+    torch.cuda.synchronize()
+    # A*xs vs A*x + A*x2 differ by A*(xs - (x + x2)): bounded by ulp(fp32) * sum|A|
+    bound = 2.0 ** -23 * float(n) ** 0.5 * 4
+    assert float((y12.double() - (y1.double() + y2.double())).abs().max()) <= bound
+
+    # (3) a slice of rows alone == the same rows of the full product, bitwise
+    lo, hi = 8192, 12288
+    part = torch.empty(hi - lo, dtype=torch.float32, device="cuda")
+    accblas.acc_gemv(F64, F32, hi - lo, n, 1.0, A[lo * n:], n, x, 1, 0.0, part, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(part, y1[lo:hi])
+
+
+def test_config_c2_gemv_16384_plain_equals_accessor(gpu):
+    torch, accblas = gpu
+    n = 16384
+    A = uniform(torch, n * n, torch.float64, 5)
+    x = uniform(torch, n, torch.float64, 6)
+    r0 = uniform(torch, n, torch.float64, 7)
+    r_plain, r_acc = r0.clone(), r0.clone()
+    accblas.gemv(F64, n, n, 1.0, A, n, x, 1, 1.0, r_plain, 1)
+    accblas.acc_gemv(F64, F64, n, n, 1.0, A, n, x, 1, 1.0, r_acc, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(r_plain, r_acc)
+    rows = [0, 5000, 16383]
+    A_rows = np.concatenate([A[r * n:(r + 1) * n].cpu().numpy() for r in rows])
+    want = oracle.exact_gemv(F64, len(rows), n, 1.0, A_rows, n, x.cpu().numpy(), 1, 1.0,
+                             r0.cpu().numpy()[rows], 1)
+    assert oracle.rel_error(want, r_acc.cpu().numpy()[rows]) <= 1e-13
+
+
+def test_config_c4_dot_2p28_fp16_storage_fp32_arithmetic(gpu):
+    """dot n = 2^28, St=fp16, Ar=fp32: the full dot equals the sum of the 8 chunk
+    dots (the multi-GPU split) within the fp32 summation tolerance, both agree with
+    an fp64 accumulation of the same fp16 data, and the error vs fp64 arithmetic on
+    the unrounded data is storage-dominated (gate 5e-3)."""
+    torch, accblas = gpu
+    n = 1 << 28
+    handle = accblas.Handle()
+    x64 = uniform(torch, n, torch.float64, 8)
+    y64 = uniform(torch, n, torch.float64, 9)
+    xh, yh = x64.half(), y64.half()
+    truth = torch.zeros(1, dtype=torch.float64, device="cuda")
+    accblas.dot(handle, F64, n, x64, 1, y64, 1, truth)
+    del x64, y64
+    full32 = torch.zeros(1, dtype=torch.float32, device="cuda")
+    full64 = torch.zeros(1, dtype=torch.float64, device="cuda")
+    accblas.acc_dot(handle, F32, F16, F32, n, xh, 1, yh, 1, full32)
+    accblas.acc_dot(handle, F64, F16, F64, n, xh, 1, yh, 1, full64)
+    chunk = n // 8
+    parts = torch.zeros(8, dtype=torch.float32, device="cuda")
+    for g in range(8):
+        accblas.acc_dot(handle, F32, F16, F32, chunk, xh[g * chunk:], 1, yh[g * chunk:], 1,
+                        parts[g:])
+    torch.cuda.synchronize()
+    scale = (n / 9.0) ** 0.5  # Q = sqrt(sum (x y)^2) ~ sqrt(n)/3
+    eps32 = 2.0 ** -24
+    assert abs(float(full32) - float(full64)) <= 64 * eps32 * scale
+    assert abs(float(parts.double().sum()) - float(full64)) <= 64 * eps32 * scale
+    rel = abs(float(full32) - float(truth)) / abs(float(truth))
+    assert rel <= 5e-3, rel
+    # deterministic mode: same bits again
+    again = torch.zeros(1, dtype=torch.float32, device="cuda")
+    accblas.acc_dot(handle, F32, F16, F32, n, xh, 1, yh, 1, again)
+    torch.cuda.synchronize()
+    assert torch.equal(again, full32)
+    handle.close()
+
+
+@pytest.mark.parametrize("upper", [False, True])
+def test_config_c5_trsv_65536_fp32_storage_fp64_arithmetic(gpu, upper):
+    """TRSV n = 65536, unit diagonal, St=fp32, Ar=fp64: residual T x - b of sampled
+    rows (fp64 on the device), no bounded spin expired, and the upper solve of the
+    transposed-and-reversed data reproduces the lower solve (the kernel solves upper
+    as the index-reversed lower system)."""
+    torch, accblas = gpu
+    n = 65536
+    T = uniform(torch, n * n, torch.float32, 10, scale=1.0 / n ** 0.5)
+    b = uniform(torch, n, torch.float32, 11)
+    if upper:
+        # U = J L^T... build the upper system from the same numbers: U[i][j] = T[j][i]
+        T = T.view(n, n).t().contiguous().view(-1)
+    x = b.clone()
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    accblas.acc_trsv(F64, F32, accblas.UPPER if upper else accblas.LOWER, accblas.UNIT, n, T,
+                     n, x, 1, helper)
+    torch.cuda.synchronize()
+    assert int(helper[0].item()) & 0xffffffff == 0xffffffff  # no spin expired
+    assert bool(torch.isfinite(x).all())
+    rows = torch.cat([torch.arange(0, 70, device="cuda"),
+                      torch.randint(0, n, (300,), device="cuda"),
+                      torch.arange(n - 70, n, device="cuda")])
+    Tr = T.view(n, n)[rows].double()
+    cols = torch.arange(n, device="cuda")
+    mask = cols[None, :] > rows[:, None] if upper else cols[None, :] < rows[:, None]
+    Tr = torch.where(mask, Tr, torch.zeros_like(Tr))
+    resid = Tr @ x.double() + x.double()[rows] - b.double()[rows]
+    rel = float(resid.abs().sum() / b.double()[rows].abs().sum())
+    assert rel <= 1e-5, rel  # x is stored in fp32: ~n^0.5 * ulp(fp32) accumulated
+
+
+def test_trsv_24000_matches_reference_shape_both_paths(gpu):
+    """The reference's default size (n = 24000, lda = 24000): vector path (lower,
+    aligned) and scalar fallback (misaligned base) give the same solution to
+    rounding."""
+    torch, accblas = gpu
+    n = 24000
+    T = uniform(torch, n * n + 1, torch.float32, 12, scale=1.0 / n ** 0.5)
+    b = uniform(torch, n, torch.float32, 13)
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    x_vec, x_scalar = b.clone(), b.clone()
+    aligned = T[:n * n].clone()
+    accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, aligned, n, x_vec, 1, helper)
+    shifted = T[1:]  # base misaligned by 4 bytes -> Vec = 1 kernel
+    shifted.copy_(aligned)
+    accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, shifted, n, x_scalar, 1, helper)
+    torch.cuda.synchronize()
+    assert rel_l1(torch, x_vec, x_scalar) <= 1e-6
