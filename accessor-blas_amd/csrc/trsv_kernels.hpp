@@ -27,15 +27,15 @@
 //   * per block: all waves stage the diagonal tile AND the last off-diagonal
 //     panel in LDS; wave 0 inverts the tile with each lane owning a column of
 //     the inverse in registers (2016 FMAs, no synchronisation, instead of a
-//     Gauss-Jordan sweep through shared memory with a sync per step) while
-//     the other waves already stream the far panels;
+//     Gauss-Jordan sweep through shared memory with a sync per step);
 //   * far panels (all but the last): 16-byte loads of the storage type,
 //     double-buffered in registers together with the x granules of the next
 //     panel, FMA in the arithmetic type, ONE cross-lane reduction at the end;
-//   * last panel + diagonal solve (the critical path): two 64 x 64 mat-vecs
-//     from LDS with lane = row (no cross-lane reduction after x_{b-1}
-//     arrives), columns split over the waves, vector entries broadcast with
-//     v_readlane, per-wave partials combined through LDS.
+//   * the last panel is folded with the inverse ahead of time,
+//     M = inv(T_bb) A_{b,b-1}, so that x_b = inv(T_bb) rhs_far - M x_{b-1}:
+//     after x_{b-1} arrives ONE 64 x 64 mat-vec from LDS is left (lane = row,
+//     columns split over the waves, vector entries broadcast with v_readlane,
+//     per-wave partials combined through LDS, one barrier).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -49,7 +49,7 @@ namespace dev {
 
 
 constexpr int trsv_tile = wave_size;  // 64
-constexpr int trsv_waves = 4;         // waves per workgroup
+constexpr int trsv_waves = 8;         // waves per workgroup
 
 using granule_word = unsigned long long;
 
@@ -69,7 +69,7 @@ __device__ unsigned long long *trsv_diag_buffer;
 #define ACCBLAS_TRSV_STAMP(_block, _slot)                                  \
     do {                                                                   \
         if (lane_id() == 0 && trsv_diag_buffer != nullptr) {               \
-            trsv_diag_buffer[(_block)*8 + (_slot)] = wall_clock64();       \
+            trsv_diag_buffer[(_block)*16 + (_slot)] = wall_clock64();       \
         }                                                                  \
     } while (false)
 #else
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     __shared__ ar_type correction[B];
     __shared__ ar_type partial_a[Waves * B];
     __shared__ ar_type partial_b[Waves * B];
+    __shared__ ar_type x_prev_lds[B];
     __shared__ std::int32_t shared_block;
 
     const int lane = lane_id();
@@ -339,11 +340,15 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
         ar_type column[B];
 #pragma unroll
         for (int i = 0; i < B; ++i) {
-            ar_type value = (lane == i) ? ar_type{1} : ar_type{0};
+            // a dependent fp64 FMA chain costs ~40 cycles per link on gfx950:
+            // four interleaved partial sums cut the row's latency by 4
+            ar_type sums[4] = {};
 #pragma unroll
             for (int k = 0; k < i; ++k) {
-                value -= tile[i * ld + k] * column[k];  // LDS broadcast read
+                sums[k & 3] += tile[i * ld + k] * column[k];  // LDS broadcast
             }
+            ar_type value = ((lane == i) ? ar_type{1} : ar_type{0}) -
+                            ((sums[0] + sums[1]) + (sums[2] + sums[3]));
             if (!UnitDiag) {
                 value = value / tile[i * ld + i];
             }
@@ -356,6 +361,49 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
             tile[lane * ld + i] = column[i];
         }
         ACCBLAS_TRSV_STAMP(block, 1);  // inverse ready
+    }
+    __syncthreads();
+
+    // ---- fold the inverse into the last panel: M = inv(T_bb) * A_{b,b-1} ---
+    // x_b = inv(T) (rhs_far - A_{b,b-1} x_{b-1}) = inv(T) rhs_far - M x_{b-1}:
+    // with M prepared here, off the critical path, only ONE mat-vec is left
+    // between the arrival of x_{b-1} and the publication of x_b. Each wave
+    // computes CW columns of M (lane = row) and overwrites the same columns of
+    // `panel`; the lane's row of the inverse is held in registers.
+    constexpr int CW = B / Waves;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    if (block > 0) {
+        ar_type inv_row[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            inv_row[k] = tile[k * ld + lane];
+        }
+        constexpr int CG = 4;  // columns per pass: independent FMA chains
+        static_assert(CW % CG == 0, "CW must be a multiple of 4");
+        for (int c0 = 0; c0 < CW; c0 += CG) {
+            const int col = wave_u * CW + c0;
+            ar_type m[CG];
+#pragma unroll
+            for (int q = 0; q < CG; ++q) {
+                m[q] = ar_type{};
+            }
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+#pragma unroll
+                for (int q = 0; q < CG; ++q) {
+                    m[q] += inv_row[k] * panel[(col + q) * ld + k];
+                }
+            }
+            // every lane of this wave has read the CG columns (program order
+            // within a wave; other waves never touch these columns)
+#pragma unroll
+            for (int q = 0; q < CG; ++q) {
+                panel[(col + q) * ld + lane] = m[q];
+            }
+        }
+    }
+    if (wave == 0) {
+        ACCBLAS_TRSV_STAMP(block, 6);  // M ready
     }
 
     // ---- far sweep: correction = sum_{c < block-1} A[block][c] x_c --------
@@ -466,55 +514,19 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     }
     __syncthreads();
 
-    // ---- critical path: last panel, then the diagonal solve ---------------
+    // ---- tail: c = inv(T) rhs_far (before the wait), then x = c - M x_{b-1} -
     // Both are 64 x 64 mat-vecs from LDS with lane = row. The columns are
     // split over the waves (CW each); a wave broadcasts its column's vector
     // entry from the lane that holds it with v_readlane (no LDS round trip),
     // and the per-wave partial results are combined through LDS in a fixed
-    // order. One wave alone needs ~2.4 us for the two fp64 mat-vecs; four
-    // waves need about a quarter of that plus two barriers.
-    constexpr int CW = B / Waves;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // order.
     if (wave == 0) {
         ACCBLAS_TRSV_STAMP(block, 3);  // all waves finished the far sweep
     }
-    ar_type rhs = own_rhs - correction[lane];
-    if (block > 0) {
-        // this wave's columns of the last panel: logical columns
-        // base - B + wave*CW + j, j < CW; lane l polls column (l % CW)
-        granule_word raw[io::words];
-        const index_type prev = base - B + wave_u * CW + (lane % CW);
-        io::load(granules, prev, raw);
-        while (!__all(io::ready(raw)) &&
-               !detail::spin_expired(spins, helper)) {
-            __builtin_amdgcn_s_sleep(1);
-            io::load(granules, prev, raw);
-        }
-        if (wave == 0) {
-            ACCBLAS_TRSV_STAMP(block, 4);  // x_{b-1} observed
-        }
-        const ar_type x_prev = static_cast<ar_type>(io::decode(raw));
-        ar_type part[2] = {};
-#pragma unroll
-        for (int j = 0; j < CW; ++j) {
-            part[j & 1] += panel[(wave_u * CW + j) * ld + lane] *
-                           detail::read_lane(x_prev, j);
-        }
-        partial_a[wave_u * B + lane] = part[0] + part[1];
-        __syncthreads();
-        ar_type sum = partial_a[lane];
-#pragma unroll
-        for (int w = 1; w < Waves; ++w) {
-            sum += partial_a[w * B + lane];
-        }
-        rhs -= sum;
-    }
-    if (!own_valid) {
-        rhs = ar_type{};
-    }
+    ar_type rhs = own_valid ? own_rhs - correction[lane] : ar_type{};
     {
-        // every wave holds the full right-hand side (lane = row); row
-        // wave*CW + j of it is column wave*CW + j of the inverse's mat-vec
+        // every wave holds the full right-hand side (lane = row); entry
+        // wave*CW + j of it multiplies column wave*CW + j of the inverse
         ar_type part[2] = {};
 #pragma unroll
         for (int j = 0; j < CW; ++j) {
@@ -523,12 +535,53 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
         }
         partial_b[wave_u * B + lane] = part[0] + part[1];
     }
+    if (block > 0) {
+        // critical path starts here. ONE wave polls the 64 granules of
+        // x_{b-1} (lane = element) and hands them to the others through LDS:
+        // four independent pollers would each add their own poll-period skew
+        // in front of the barrier, and their loads would queue beside the
+        // critical one.
+        if (wave == 0) {
+            granule_word raw[io::words];
+            const index_type prev = base - B + lane;  // always < n
+            io::load(granules, prev, raw);
+            while (!__all(io::ready(raw)) &&
+                   !detail::spin_expired(spins, helper)) {
+                io::load(granules, prev, raw);
+            }
+            ACCBLAS_TRSV_STAMP(block, 4);  // x_{b-1} observed
+            x_prev_lds[lane] = static_cast<ar_type>(io::decode(raw));
+        }
+        __syncthreads();
+        if (wave == 0) {
+            ACCBLAS_TRSV_STAMP(block, 7);  // x_{b-1} handed to all waves
+        }
+        ar_type part[2] = {};
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+            part[j & 1] += panel[(wave_u * CW + j) * ld + lane] *
+                           x_prev_lds[wave_u * CW + j];
+        }
+        partial_a[wave_u * B + lane] = part[0] + part[1];
+        if (wave == 0) {
+            ACCBLAS_TRSV_STAMP(block, 8);  // wave 0 mat-vec share done
+        }
+    }
     __syncthreads();
     if (wave == 0) {
+        ACCBLAS_TRSV_STAMP(block, 9);  // all mat-vec shares done
         ar_type sum = partial_b[lane];
 #pragma unroll
         for (int w = 1; w < Waves; ++w) {
             sum += partial_b[w * B + lane];
+        }
+        if (block > 0) {
+            ar_type fold = partial_a[lane];
+#pragma unroll
+            for (int w = 1; w < Waves; ++w) {
+                fold += partial_a[w * B + lane];
+            }
+            sum -= fold;
         }
         const st_type solution = static_cast<st_type>(sum);
         if (own_valid) {

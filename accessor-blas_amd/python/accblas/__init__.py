@@ -95,6 +95,14 @@ def load():
         raise FileNotFoundError(
             f"{LIB_PATH} not found: build it with `make -C {PACKAGE_ROOT}` "
             "(or __graft_entry__.build()); there is no CPU fallback")
+    # PyTorch ships its own copy of the HIP runtime. Whichever libamdhip64 is
+    # mapped first serves the whole process, and device pointers of one copy
+    # mean nothing to the other ("no ROCm-capable device is detected" at the
+    # first launch), so make sure torch's copy is in before ours resolves.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol

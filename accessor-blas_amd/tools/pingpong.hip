@@ -81,8 +81,34 @@ void run(const char *name, word *g, int hops, int nb, int work, double *sink)
                 best * 1e3, best * 1e3 / hops);
 }
 
+// effective shader clock while a kernel with `active` busy waves per block runs:
+// ratio of s_memtime (shader cycles) to s_memrealtime (100 MHz)
+__global__ void clock_probe(unsigned long long *out, int iters, double *sink)
+{
+    double acc = threadIdx.x;
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) acc = acc * 1.0000001 + 0.5;
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = w1 - w0; }
+    if (acc == 12345.678) *sink = acc;
+}
+
 int main(int argc, char **argv)
 {
+    {
+        unsigned long long *out; double *sink2;
+        CHECK(hipMalloc(&out, 4096 * 16)); CHECK(hipMalloc(&sink2, 8));
+        for (int blocks : {1, 16, 256, 2048}) {
+            for (int rep = 0; rep < 2; ++rep) {
+                clock_probe<<<blocks, 64>>>(out, 200000, sink2);
+                CHECK(hipDeviceSynchronize());
+            }
+            unsigned long long h[2];
+            CHECK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost));
+            std::printf("clock probe blocks=%4d: %llu shader cycles in %llu x10ns -> %.0f MHz, %.1f cycles per dependent f64 fma iteration\n",
+                        blocks, h[0], h[1], h[0] / (h[1] * 0.01), double(h[0]) / 200000);
+        }
+    }
     const int hops = argc > 1 ? std::atoi(argv[1]) : 2000;
     word *g; double *sink;
     CHECK(hipMalloc(&g, (size_t)hops * 64 * 8));

@@ -111,23 +111,24 @@ int main(int argc, char **argv)
     // phase stamps of the production shape (100 MHz clock -> us)
     {
         unsigned long long *diag;
-        CHECK(hipMalloc(&diag, size_t(blocks) * 64));
-        CHECK(hipMemset(diag, 0, size_t(blocks) * 64));
+        CHECK(hipMalloc(&diag, size_t(blocks) * 128));
+        CHECK(hipMemset(diag, 0, size_t(blocks) * 128));
         CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_diag_buffer), &diag, sizeof(diag)));
         CHECK(hipMemcpy(x, x0, n * sizeof(st_type), hipMemcpyDeviceToDevice));
         entries[0].run();
         CHECK(hipDeviceSynchronize());
-        std::vector<unsigned long long> st(size_t(blocks) * 8);
+        std::vector<unsigned long long> st(size_t(blocks) * 16);
         CHECK(hipMemcpy(st.data(), diag, st.size() * 8, hipMemcpyDeviceToHost));
         const unsigned long long t0 = st[0];
-        auto us = [&](unsigned b, int slot) { return (double)(long long)(st[b * 8 + slot] - t0) * 0.01; };
+        auto us = [&](unsigned b, int slot) { return (double)(long long)(st[b * 16 + slot] - t0) * 0.01; };
         std::printf("block: ticket  inv_done  w0_far  all_far  seen  published | hop  seen-prev_pub  pub-seen  allfar-prevprev_pub\n");
         for (unsigned b : {0u, 1u, 2u, 3u, 10u, 11u, 12u, 100u, 101u, 102u, 200u, 201u, 300u, 301u, 500u, 501u, 800u, 801u, 1000u, 1001u}) {
             if (b >= blocks) continue;
-            std::printf("%5u: %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f | %6.2f %6.2f %6.2f %6.2f\n", b, us(b, 0), us(b, 1), us(b, 2),
+            std::printf("%5u: %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f | %6.2f %6.2f %6.2f %6.2f | seen->bar1 %5.2f matvec %5.2f bar2 %5.2f sum+pub %5.2f\n", b, us(b, 0), us(b, 1), us(b, 2),
                         us(b, 3), us(b, 4), us(b, 5), b ? us(b, 5) - us(b - 1, 5) : 0.0,
                         b ? us(b, 4) - us(b - 1, 5) : 0.0, us(b, 5) - us(b, 4),
-                        b > 1 ? us(b, 3) - us(b - 2, 5) : 0.0);
+                        b > 1 ? us(b, 3) - us(b - 2, 5) : 0.0, us(b, 7) - us(b, 4), us(b, 8) - us(b, 7),
+                        us(b, 9) - us(b, 8), us(b, 5) - us(b, 9));
         }
         diag = nullptr;
         CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_diag_buffer), &diag, sizeof(diag)));
