@@ -45,6 +45,70 @@ struct entry {
     std::string name;
     std::function<void()> run;
 };
+// Experimental variant (north_star: "LDS staging of x-vector tiles"): every
+// wave owns R rows, all waves of the workgroup sweep the same columns, and the
+// x tile is staged ONCE per workgroup in LDS, already widened to the
+// arithmetic type, double-buffered. Requires cols % TileCols == 0.
+template <int Waves, int R, int U, int TileCols, bool NT>
+__global__ __launch_bounds__(Waves * 64) void gemv_lds(double alpha, c_range mtx, c_range x,
+                                                      double beta, range res)
+{
+    constexpr int Vec = 4;
+    __shared__ double xs[2][TileCols];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rows = mtx.length(0), cols = mtx.length(1);
+    const long row0 = (long(blockIdx.x) * Waves + wave) * R;
+    const float *a = mtx->get_const_storage();
+    const float *xp = x->get_const_storage();
+    const long lda = mtx->stride(0);
+    const float *row_ptr[R];
+    for (int j = 0; j < R; ++j) row_ptr[j] = a + (row0 + j < rows ? row0 + j : rows - 1) * lda;
+    double acc[R] = {};
+    auto stage = [&](long tile, int buf) {
+        for (int i = threadIdx.x * Vec; i < TileCols; i += Waves * 64 * Vec) {
+            const auto v = load_packed<Vec, false>(xp + tile * TileCols + i);
+            for (int k = 0; k < Vec; ++k) xs[buf][i + k] = double(v[k]);
+        }
+    };
+    const long tiles = cols / TileCols;
+    stage(0, 0);
+    for (long t = 0; t < tiles; ++t) {
+        __syncthreads();
+        if (t + 1 < tiles) stage(t + 1, (t + 1) & 1);
+        const double *xt = xs[t & 1];
+        for (int c0 = 0; c0 < TileCols; c0 += 64 * Vec * U) {
+            typename packed<float, Vec>::type av[R][U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    av[j][u] = load_packed<Vec, NT>(row_ptr[j] + t * TileCols + c0 + u * 64 * Vec + lane * Vec);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < Vec; ++k) {
+                    const double xk = xt[c0 + u * 64 * Vec + lane * Vec + k];
+#pragma unroll
+                    for (int j = 0; j < R; ++j) acc[j] += double(av[j][u][k]) * xk;
+                }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const double total = wave_reduce_sum(acc[j]);
+        if (lane == 0 && row0 + j < rows) res(row0 + j, 0) = alpha * total + beta * res(row0 + j, 0);
+    }
+}
+
+template <int Waves, int R, int U, int TileCols, bool NT>
+entry make_lds(const char *name, c_range m, c_range x, range r)
+{
+    return {name, [=]() {
+                const unsigned grid = unsigned((m.length(0) + Waves * R - 1) / (Waves * R));
+                gemv_lds<Waves, R, U, TileCols, NT><<<grid, Waves * 64>>>(1.0, m, x, 1.0, r);
+            }};
+}
+
 
 template <typename Config>
 entry make(const char *name, c_range m, c_range x, range r)
@@ -88,6 +152,16 @@ int main(int argc, char **argv)
         make<gemv_config<8, 1, 2, 4, false>>("w8 wpr1 r2 u4", m, xv, rv),
         make<gemv_config<4, 4, 1, 8, false>>("w4 wpr4 r1 u8", m, xv, rv),
     };
+    entries.push_back(make_lds<4, 4, 2, 2048, true>("LDS-x w4 r4 u2 t2048 nt", m, xv, rv));
+    entries.push_back(make_lds<8, 4, 2, 2048, true>("LDS-x w8 r4 u2 t2048 nt", m, xv, rv));
+    entries.push_back(make_lds<8, 2, 4, 4096, true>("LDS-x w8 r2 u4 t4096 nt", m, xv, rv));
+    entries.push_back(make_lds<4, 8, 1, 2048, true>("LDS-x w4 r8 u1 t2048 nt", m, xv, rv));
+    entries.push_back(make<gemv_config<8, 8, 2, 4, true>>("w8 wpr8 r2 u4 nt", m, xv, rv));
+    entries.push_back(make<gemv_config<8, 8, 8, 1, true>>("w8 wpr8 r8 u1 nt", m, xv, rv));
+    entries.push_back(make<gemv_config<8, 8, 4, 4, true>>("w8 wpr8 r4 u4 nt", m, xv, rv));
+    entries.push_back(make<gemv_config<16, 16, 4, 2, true>>("w16 wpr16 r4 u2 nt", m, xv, rv));
+    entries.push_back(make<gemv_config<8, 4, 4, 2, true>>("w8 wpr4 r4 u2 nt", m, xv, rv));
+    entries.push_back(make<gemv_config<8, 8, 4, 2, true>>("w8 wpr8 r4 u2 nt (default)", m, xv, rv));
     hipEvent_t start, stop;
     CHECK(hipEventCreate(&start));
     CHECK(hipEventCreate(&stop));

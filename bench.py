@@ -79,6 +79,33 @@ def cpu_baseline(oracle, ar, A_rows, lda, x, res_rows, threads):
     return (2.0 * rows * cols / t_all / 1e9, 2.0 * one_rows * cols / t_one / 1e9, res_all)
 
 
+class HostStagedCollectives:
+    """torch.distributed look-alike for the gloo rehearsal: device tensors are
+    staged through the host for the collective (gloo has no device path for
+    them). The product path uses torch.distributed (RCCL) directly."""
+
+    def __init__(self, dist):
+        self._dist = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def get_world_size(self, group=None):
+        return self._dist.get_world_size(group)
+
+    def get_rank(self, group=None):
+        return self._dist.get_rank(group)
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def all_reduce(self, tensor, op=None, group=None):
+        host = tensor.cpu()
+        self._dist.all_reduce(host, op=op, group=group)
+        tensor.copy_(host)
+
+    def destroy_process_group(self):
+        self._dist.destroy_process_group()
+
+
 def event_time_us(accblas, torch, fn, stream, reps=5):
     """min-of-reps HIP-event time of fn() in microseconds."""
     fn()
@@ -230,14 +257,24 @@ def main():
             sys.exit("--gpus N > 1 must be launched with torch.distributed.run "
                      "(one process per GPU)")
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; ACCBLAS_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box
+    # only) lets several ranks share device 0 and use gloo, because RCCL needs
+    # one device per rank
+    share_gpu = os.environ.get("ACCBLAS_BENCH_SHARE_GPU") == "1"
+    device_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     dist = None
     if world > 1:
-        import torch.distributed as dist
+        import torch.distributed as torch_dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=dev)
+        if share_gpu:
+            torch_dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist = HostStagedCollectives(torch_dist)
+        else:
+            torch_dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                          device_id=dev)
+            dist = torch_dist
 
     codes = {"f16": accblas.F16, "f32": accblas.F32, "f64": accblas.F64}
     st, ar = codes[args.st], codes[args.ar]

@@ -51,6 +51,10 @@ def main():
     with open(os.path.join(PROF, "traffic.json"), "w") as f:
         json.dump({"source": f"profiles/{tag}_gemv_pmc.json",
                    "gemv_vec_bytes_per_launch": read_bytes + write_bytes}, f, indent=1)
+    for name in ("dot", "trsv"):
+        src = os.path.join(OUT, f"prof_{name}", f"{name}_kernel_stats.csv")
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(PROF, f"{tag}_{name}_kernel_stats.csv"))
     print(json.dumps(summary, indent=1))
 
 
