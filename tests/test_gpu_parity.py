@@ -313,3 +313,69 @@ def test_trsv_manufactured_solution_strided(gpu):
     got = dx.cpu().numpy()
     assert np.all(got[1::incx] == 0.0)
     assert oracle.rel_error(x_true, got[::incx]) <= 1e-11
+
+
+# ------------------------------------------------------------- streams and graphs
+def test_launches_on_a_side_stream_and_hipgraph_replay(gpu):
+    """Launchers take an explicit stream, allocate nothing per call (TRSV: after the
+    first call on that stream) and synchronise nothing, so a GEMV -> dot -> TRSV
+    sequence can be captured into a HIP graph and replayed."""
+    torch, accblas = gpu
+    n, lda = 512, 512
+    rng = np.random.default_rng(40)
+    A = to_dev(torch, oracle.convert(rng.uniform(-1, 1, n * lda) / 16.0, F32))
+    x = to_dev(torch, oracle.convert(rng.uniform(-1, 1, n), F32))
+    res0 = to_dev(torch, oracle.convert(rng.uniform(-1, 1, n), F32))
+    handle = accblas.Handle()
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+
+    def sequence(stream, res, dot_out, sol):
+        accblas.acc_gemv(F64, F32, n, n, 1.0, A, lda, x, 1, 1.0, res, 1, stream)
+        accblas.acc_dot(handle, F64, F32, F64, n, res, 1, x, 1, dot_out, stream)
+        accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, A, lda, sol, 1, helper,
+                         stream)
+
+    side = torch.cuda.Stream()
+    want_res, want_sol = res0.clone(), res0.clone()
+    want_dot = torch.zeros(1, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        sequence(side, want_res, want_dot, want_sol)  # also sizes the TRSV workspace
+    side.synchronize()
+
+    got_res, got_sol = res0.clone(), res0.clone()
+    got_dot = torch.zeros(1, dtype=torch.float64, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        sequence(torch.cuda.current_stream(), got_res, got_dot, got_sol)
+    got_res.copy_(res0)
+    got_sol.copy_(res0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got_res, want_res)
+    assert torch.equal(got_dot, want_dot)
+    assert torch.equal(got_sol, want_sol)
+    # replay again from the same inputs: identical bits (deterministic dot, re-armed
+    # tickets and granules)
+    got_res.copy_(res0)
+    got_sol.copy_(res0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got_res, want_res) and torch.equal(got_dot, want_dot)
+    assert torch.equal(got_sol, want_sol)
+    handle.close()
+
+
+def test_trsv_workspace_grows_and_helper_reports_no_timeout(gpu):
+    torch, accblas = gpu
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for n in (64, 3000, 700, 9000):  # grow, shrink, grow again on the default stream
+        A = to_dev(torch, oracle.convert(triangular_system(n, n, False, n), F64))
+        b = make_inputs(50 + n, n, F64)
+        want = oracle.exact_trsv(F64, False, True, n, A.cpu().numpy(), n, b, 1)
+        dx = to_dev(torch, b)
+        accblas.acc_trsv(F64, F64, accblas.LOWER, accblas.UNIT, n, A, n, dx, 1, helper)
+        torch.cuda.synchronize()
+        assert int(helper[0].item()) & 0xffffffff == 0xffffffff
+        assert oracle.rel_error(want, dx.cpu().numpy()) <= 1e-11
