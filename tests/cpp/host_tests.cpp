@@ -10,6 +10,8 @@
 #include <accessor/index_span.hpp>
 #include <accessor/range.hpp>
 #include <accessor/reduced_row_major.hpp>
+#include <accessor/row_major.hpp>
+#include <accessor/scaled_reduced_row_major.hpp>
 
 #include "float16.hpp"
 #include "matrix_helper.hpp"
@@ -191,8 +193,54 @@ void runtime_checks()
 }
 
 
+void other_accessor_kinds()
+{
+    using namespace gko::acc;
+    // row_major: real references, same range interface
+    double d[12];
+    for (int i = 0; i < 12; ++i) {
+        d[i] = i;
+    }
+    range<row_major<double, 2>> r(std::array<size_type, 2>{{3, 3}}, d,
+                                  std::array<size_type, 1>{{4}});
+    static_assert(std::is_same<decltype(r(0, 0)), double &>::value, "");
+    r(1, 2) += 10;
+    CHECK(d[6] == 16.0 && r.length(0) == 3 && r->get_stride()[0] == 4);
+    CHECK(r(index_span{1, 3}, index_span{1, 3})(0, 0) == 5.0);
+    auto rc = r->to_const();
+    static_assert(std::is_same<decltype(rc(0, 0)), const double &>::value, "");
+    CHECK(rc(2, 2) == 10.0);
+    range<row_major<double, 3>> r3(std::array<size_type, 3>{{2, 2, 3}}, d);
+    CHECK(r3(1, 1, 2) == 11.0);
+
+    // scaled_reduced_row_major: value = stored * scalar(masked indices)
+    std::int32_t st[6] = {100, 200, 300, 400, 500, 600};
+    double per_col[3] = {0.01, 0.1, 1.0};
+    using col_scaled = scaled_reduced_row_major<2, double, std::int32_t, 0b10>;
+    range<col_scaled> s(std::array<size_type, 2>{{2, 3}}, st,
+                        std::array<size_type, 1>{{3}}, per_col);
+    static_assert(std::is_trivially_copyable<range<col_scaled>>::value, "");
+    static_assert(std::is_same<decltype(s(0, 0) * s(1, 1) + 2.0), double>::value, "");
+    CHECK(static_cast<double>(s(0, 0)) == 100 * 0.01);
+    CHECK(static_cast<double>(s(1, 1)) == 500 * 0.1);
+    s(0, 1) = 7.77;  // stored as int(7.77 / 0.1) = 77
+    CHECK(st[1] == 77 && static_cast<double>(s(0, 1)) == 77 * 0.1);
+    auto sc = s->to_const();
+    static_assert(std::is_same<decltype(sc(0, 0)), double>::value, "");
+    CHECK(sc(1, 2) == 600.0 && s->read_scalar_masked(1, 2) == 1.0);
+    s->write_scalar_masked(2.0, 0, 2);
+    CHECK(sc(1, 2) == 1200.0);
+    double per_row[2] = {2.0, 3.0};
+    range<scaled_reduced_row_major<2, double, std::int32_t, 0b01>> s2(
+        std::array<size_type, 2>{{2, 3}}, st, per_row);
+    CHECK(static_cast<double>(s2(0, 2)) == 600.0 &&
+          static_cast<double>(s2(1, 0)) == 1200.0);
+}
+
+
 int main()
 {
+    other_accessor_kinds();
     accessor_contract<double, double>();
     accessor_contract<double, float>();
     accessor_contract<float, float>();
