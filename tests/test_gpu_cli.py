@@ -1,0 +1,92 @@
+"""GPU tests of the three drop-in benchmark executables: header and column
+layout of the reference's CSV (`/root/reference/cuda/gemv_benchmark.cu:196-250`,
+`dot_benchmark.cu:146-235`, `trsv_benchmark.cu:184-235`), error columns with the
+magnitudes the reference publishes, exact zeros for Acc<T,T> vs
+plain (same bits), and the added flags. Run with -m gpu."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+BIN = os.path.join(REPO, "accessor-blas_amd", "bin")
+
+
+def run(name, *args):
+    out = subprocess.run([os.path.join(BIN, name), *args], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().split("\n")
+    return lines[0].split(";"), [line.split(";") for line in lines[1:]]
+
+
+def test_gemv_benchmark_error_mode():
+    header, rows = run("gemv_benchmark", "--error", "--size=1500", "--start=500",
+                       "--step=500")
+    assert header == ["Num rows", "Error GEMV fp64", "Error GEMV fp32",
+                      "Error GEMV Acc<fp64, fp64>", "Error GEMV Acc<fp64, fp32>",
+                      "Error GEMV Acc<fp32, fp32>", "Error ROCBLAS GEMV fp64",
+                      "Error ROCBLAS GEMV fp32"]
+    assert [r[0] for r in rows] == ["+500", "+1000", "+1500"]  # showpos, as the reference
+    for r in rows:
+        values = [float(v) for v in r[1:]]
+        assert values[0] == 0.0 and values[2] == 0.0        # reference itself, Acc<fp64,fp64>
+        assert values[1] == values[4]                        # plain fp32 == Acc<fp32,fp32>
+        assert 2.5e-8 <= values[3] <= 5.5e-8                 # published: 3.8-4.2e-8
+        assert 6e-8 <= values[1] <= 2e-7                     # published: 8.4e-8 .. 1.5e-7
+        assert values[5] <= 1e-14 and values[6] <= 1e-6      # rocBLAS columns
+        assert r[1] == "+0.0000000000000000e+00"             # precision(16), scientific
+
+
+def test_gemv_benchmark_timing_mode_with_rates_and_fp16():
+    header, rows = run("gemv_benchmark", "--size=4096", "--only=4096", "--rates")
+    assert header[:8] == ["Num rows", "GEMV fp64", "GEMV fp32", "GEMV Acc<fp64, fp64>",
+                          "GEMV Acc<fp64, fp32>", "GEMV Acc<fp32, fp32>",
+                          "ROCBLAS GEMV fp64", "ROCBLAS GEMV fp32"]
+    assert len(header) == 8 + 3 * 7 and header[8] == "GFLOP/s GEMV fp64"
+    assert len(rows) == 1 and len(rows[0]) == len(header)
+    times = [float(v) for v in rows[0][1:8]]
+    assert all(0.0 < t < 5.0 for t in times)  # milliseconds
+    header16, rows16 = run("gemv_benchmark", "--error", "--size=1024", "--only=1024",
+                           "--st=fp16", "--ar=fp32")
+    assert "Error GEMV Acc<fp32, fp16>" in header16
+    err = float(rows16[0][header16.index("Error GEMV Acc<fp32, fp16>")])
+    assert 1e-5 <= err <= 2e-3  # storage-rounding dominated
+
+
+def test_dot_benchmark_timing_and_detailed_error():
+    header, rows = run("dot_benchmark", "--size=3000000")
+    assert header[0] == "Vector Size" and header[1] == "DOT fp64"
+    assert header[8] == "Error DOT fp64" and len(header) == 15
+    assert [r[0] for r in rows] == ["1000000", "3000000"]
+    for r in rows:
+        errors = [float(v) for v in r[8:]]
+        assert errors[0] == 0.0 and errors[2] == 0.0
+        assert errors[3] <= 5e-6 and errors[1] <= 1e-4 and errors[5] <= 1e-12
+    header, rows = run("dot_benchmark", "--error", "--size=1000000")
+    assert header == ["Vector Size"] + ["Error " + n for n in (
+        "DOT fp64", "DOT fp32", "DOT Acc<fp64, fp64>", "DOT Acc<fp64, fp32>",
+        "DOT Acc<fp32, fp32>", "ROCBLAS DOT fp64", "ROCBLAS DOT fp32")]
+    separator = [i for i, r in enumerate(rows) if r[0].startswith("-----")]
+    assert len(separator) == 1
+    raw = rows[separator[0] + 1:]
+    assert raw[0][:2] == ["Random iter", "Vector Size"] and len(raw) == 1 + 10
+    # first random iteration = the reference generator's vectors: config C1's value
+    assert abs(float(raw[1][2]) - 154.655753144421740) <= 1e-12 * 154.655753144421740
+
+
+@pytest.mark.parametrize("extra", [[], ["--uplo=lower"], ["--diag=non-unit"]])
+def test_trsv_benchmark_error_mode(extra):
+    header, rows = run("trsv_benchmark", "--error", "--size=1300", "--start=650",
+                       "--step=650", *extra)
+    assert header == ["Num rows"] + ["Error " + n for n in (
+        "TRSV fp64", "TRSV fp32", "TRSV Acc<fp64, fp64>", "TRSV Acc<fp64, fp32>",
+        "TRSV Acc<fp32, fp32>", "ROCBLAS TRSV fp64", "ROCBLAS TRSV fp32")]
+    for r in rows:
+        values = [float(v) for v in r[1:]]
+        assert values[0] == 0.0 and values[2] == 0.0
+        assert values[1] == values[4]
+        assert values[3] <= values[1] <= 1e-3   # fp64 arithmetic never worse than fp32
+        assert values[5] <= 1e-11
