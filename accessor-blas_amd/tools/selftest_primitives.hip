@@ -1,0 +1,134 @@
+// GPU self-test of csrc/wave_primitives.hpp (the gfx950 replacements of the
+// reference's `cuda/kernel_utils.cuh` and `cuda/atomics.cuh`): 64-lane
+// reductions, workgroup reduction, native and compare-and-swap atomic_add,
+// agent-scope store/load helpers and the TRSV read_lane broadcast. Built by the
+// Makefile, run by tests/test_gpu_primitives.py. Prints "primitives ok" and
+// exits 0 when every check holds.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "trsv_kernels.hpp"
+#include "wave_primitives.hpp"
+
+#define CHECK(call)                                                        \
+    do {                                                                   \
+        hipError_t e = (call);                                             \
+        if (e != hipSuccess) {                                             \
+            std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__,         \
+                         hipGetErrorString(e));                            \
+            std::exit(2);                                                  \
+        }                                                                  \
+    } while (0)
+
+using namespace accblas::dev;
+
+// an 8-byte type without a native atomic: exercises the CAS fallback
+struct fixed_point {
+    long long raw;
+    __host__ __device__ fixed_point operator+(fixed_point o) const
+    {
+        return fixed_point{raw + o.raw};
+    }
+};
+
+struct results {
+    double wave_sum[4];        // per wave of a 256-thread block
+    double wave_all[256];      // group_all_reduce<64> result seen by every lane
+    double group16[256];       // group_all_reduce<16>
+    double block_sum;          // block_reduce_sum<4>
+    float atomic_f32;          // 4096 * 256 adds of 0.25
+    double atomic_f64;
+    unsigned int atomic_u32;
+    fixed_point atomic_cas;    // CAS fallback
+    double lane_broadcast[64];
+    double agent_roundtrip;
+};
+
+__global__ __launch_bounds__(256) void reductions(results *out)
+{
+    __shared__ double scratch[4];
+    const double value = threadIdx.x + 1;  // 1..256
+    const double w = wave_reduce_sum(value);
+    if (lane_id() == 0) {
+        out->wave_sum[wave_id()] = w;
+    }
+    out->wave_all[threadIdx.x] =
+        group_all_reduce<64>(value, [](double a, double b) { return a + b; });
+    out->group16[threadIdx.x] =
+        group_all_reduce<16>(value, [](double a, double b) { return a + b; });
+    const double total = block_reduce_sum<4>(value, scratch);
+    if (threadIdx.x == 0) {
+        out->block_sum = total;
+        store_agent(&out->agent_roundtrip, 3.25);
+        drain_vmem();
+        out->agent_roundtrip = load_agent(&out->agent_roundtrip) * 2;
+    }
+    if (threadIdx.x < 64) {
+        // lane l holds l * 1.5; every lane reads lane (63 - l)'s value in turn
+        const double mine = threadIdx.x * 1.5;
+        double acc = 0;
+        for (int src = 0; src < 64; ++src) {
+            const double v = kernel::detail::read_lane(mine, src);
+            if (src == 63 - (int)threadIdx.x) {
+                acc = v;
+            }
+        }
+        out->lane_broadcast[threadIdx.x] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void atomics(results *out)
+{
+    atomic_add(&out->atomic_f32, 0.25f);
+    atomic_add(&out->atomic_f64, 0.5);
+    atomic_add(&out->atomic_u32, 1u);
+    atomic_add(&out->atomic_cas, fixed_point{3});
+}
+
+int main()
+{
+    results *dev;
+    CHECK(hipMalloc(&dev, sizeof(results)));
+    CHECK(hipMemset(dev, 0, sizeof(results)));
+    reductions<<<1, 256>>>(dev);
+    atomics<<<4096, 256>>>(dev);
+    CHECK(hipDeviceSynchronize());
+    results host;
+    CHECK(hipMemcpy(&host, dev, sizeof(results), hipMemcpyDeviceToHost));
+    int failures = 0;
+    auto expect = [&](bool ok, const char *what) {
+        if (!ok) {
+            std::printf("FAILED: %s\n", what);
+            ++failures;
+        }
+    };
+    for (int w = 0; w < 4; ++w) {
+        const double want = 64.0 * (64 * w) + 64.0 * 65 / 2;  // sum of 64w+1 .. 64w+64
+        expect(host.wave_sum[w] == want, "wave_reduce_sum");
+        for (int l = 0; l < 64; ++l) {
+            expect(host.wave_all[64 * w + l] == want, "group_all_reduce<64>");
+        }
+    }
+    for (int t = 0; t < 256; ++t) {
+        const int g = t / 16;
+        const double want = 16.0 * (16 * g) + 16.0 * 17 / 2;
+        expect(host.group16[t] == want, "group_all_reduce<16>");
+    }
+    expect(host.block_sum == 256.0 * 257 / 2, "block_reduce_sum");
+    const double adds = 4096.0 * 256;
+    expect(host.atomic_f32 == 0.25f * adds, "atomic_add float");
+    expect(host.atomic_f64 == 0.5 * adds, "atomic_add double");
+    expect(host.atomic_u32 == (unsigned)adds, "atomic_add unsigned");
+    expect(host.atomic_cas.raw == 3 * (long long)adds, "atomic_add CAS fallback");
+    for (int l = 0; l < 64; ++l) {
+        expect(host.lane_broadcast[l] == (63 - l) * 1.5, "read_lane");
+    }
+    expect(host.agent_roundtrip == 6.5, "store_agent/load_agent");
+    if (failures == 0) {
+        std::printf("primitives ok\n");
+    }
+    return failures == 0 ? 0 : 1;
+}
