@@ -256,11 +256,12 @@ __global__ __launch_bounds__(Waves *wave_size) void gemv_generic(
 
 
 /** Production shape of the vector kernel, chosen by measurement on MI355X
- *  (tools/tune_gemv.hip, profiles/r01_tune_gemv.txt): 8 waves sweep 4 rows
- *  together, 2 x 16-byte loads per row and lane in flight, non-temporal
- *  matrix loads (the matrix is read once: nt gained 12 % over default-policy
- *  loads at 32768^2, 6.89 vs 6.17 TB/s). */
-using gemv_default_config = gemv_config<8, 8, 4, 2, true>;
+ *  (tools/tune_gemv.hip, profiles/r01_tune_gemv*.txt): 8 waves in two groups of
+ *  4, each group sweeps 4 rows together, 2 x 16-byte loads per row and lane in
+ *  flight, non-temporal matrix loads (the matrix is read once: nt gained 12 %
+ *  over default-policy loads at 32768^2, 6.89 vs 6.17 TB/s). Every nt shape
+ *  with 8-16 loads in flight per lane lands within 2 % of this one. */
+using gemv_default_config = gemv_config<8, 4, 4, 2, true>;
 
 
 /**

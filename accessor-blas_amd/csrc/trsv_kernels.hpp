@@ -50,6 +50,7 @@ namespace dev {
 
 constexpr int trsv_tile = wave_size;  // 64
 constexpr int trsv_waves = 8;         // waves per workgroup
+constexpr int trsv_prefetch_depth = 2;  // far panels in flight per wave
 
 using granule_word = unsigned long long;
 
@@ -485,19 +486,29 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
         }
     };
     if (far_end > 0) {
-        stage even, odd;
-        issue(0, even);
-        index_type cb = 0;
-        for (; cb + 1 < far_end; cb += 2) {
-            issue(cb + 1, odd);
-            consume(cb, even);
-            if (cb + 2 < far_end) {
-                issue(cb + 2, even);
+        // ring of `depth` stages: the matrix data of the next `depth` panels
+        // is always in flight (it does not depend on x); each hop of the
+        // front triggers one new 16 KB panel load per block, and its latency
+        // under load (2-3 us) must not stall the sweep
+        constexpr int depth = trsv_prefetch_depth;
+        stage ring[depth];
+#pragma unroll
+        for (int d = 0; d < depth; ++d) {
+            if (d < far_end) {
+                issue(d, ring[d]);
             }
-            consume(cb + 1, odd);
         }
-        if (cb < far_end) {
-            consume(cb, even);
+        for (index_type cb0 = 0; cb0 < far_end; cb0 += depth) {
+#pragma unroll
+            for (int d = 0; d < depth; ++d) {
+                const index_type cb = cb0 + d;
+                if (cb < far_end) {
+                    consume(cb, ring[d]);
+                    if (cb + depth < far_end) {
+                        issue(cb + depth, ring[d]);
+                    }
+                }
+            }
         }
     }
 #pragma unroll

@@ -133,35 +133,34 @@ int main(int argc, char **argv)
     c_range xv(sz{{n, 1}}, (const st_type *)x, st{{1}});
     range rv(sz{{n, 1}}, res, st{{1}});
 
-    std::vector<entry> entries = {
-        //            waves wpr rows unroll nt
-        make<gemv_config<4, 4, 4, 2, false>>("w4 wpr4 r4 u2", m, xv, rv),
-        make<gemv_config<4, 4, 4, 2, true>>("w4 wpr4 r4 u2 nt", m, xv, rv),
-        make<gemv_config<4, 1, 4, 2, false>>("w4 wpr1 r4 u2", m, xv, rv),
-        make<gemv_config<4, 1, 4, 2, true>>("w4 wpr1 r4 u2 nt", m, xv, rv),
-        make<gemv_config<4, 4, 2, 4, false>>("w4 wpr4 r2 u4", m, xv, rv),
-        make<gemv_config<4, 4, 8, 1, false>>("w4 wpr4 r8 u1", m, xv, rv),
-        make<gemv_config<4, 4, 8, 2, false>>("w4 wpr4 r8 u2", m, xv, rv),
-        make<gemv_config<8, 8, 4, 2, false>>("w8 wpr8 r4 u2", m, xv, rv),
-        make<gemv_config<8, 8, 4, 2, true>>("w8 wpr8 r4 u2 nt", m, xv, rv),
-        make<gemv_config<4, 4, 4, 4, false>>("w4 wpr4 r4 u4", m, xv, rv),
-        make<gemv_config<4, 4, 4, 1, false>>("w4 wpr4 r4 u1", m, xv, rv),
-        make<gemv_config<2, 2, 4, 2, false>>("w2 wpr2 r4 u2", m, xv, rv),
-        make<gemv_config<16, 16, 4, 2, false>>("w16 wpr16 r4 u2", m, xv, rv),
-        make<gemv_config<4, 2, 4, 2, false>>("w4 wpr2 r4 u2", m, xv, rv),
-        make<gemv_config<8, 1, 2, 4, false>>("w8 wpr1 r2 u4", m, xv, rv),
-        make<gemv_config<4, 4, 1, 8, false>>("w4 wpr4 r1 u8", m, xv, rv),
-    };
-    entries.push_back(make_lds<4, 4, 2, 2048, true>("LDS-x w4 r4 u2 t2048 nt", m, xv, rv));
-    entries.push_back(make_lds<8, 4, 2, 2048, true>("LDS-x w8 r4 u2 t2048 nt", m, xv, rv));
-    entries.push_back(make_lds<8, 2, 4, 4096, true>("LDS-x w8 r2 u4 t4096 nt", m, xv, rv));
-    entries.push_back(make_lds<4, 8, 1, 2048, true>("LDS-x w4 r8 u1 t2048 nt", m, xv, rv));
-    entries.push_back(make<gemv_config<8, 8, 2, 4, true>>("w8 wpr8 r2 u4 nt", m, xv, rv));
-    entries.push_back(make<gemv_config<8, 8, 8, 1, true>>("w8 wpr8 r8 u1 nt", m, xv, rv));
-    entries.push_back(make<gemv_config<8, 8, 4, 4, true>>("w8 wpr8 r4 u4 nt", m, xv, rv));
-    entries.push_back(make<gemv_config<16, 16, 4, 2, true>>("w16 wpr16 r4 u2 nt", m, xv, rv));
-    entries.push_back(make<gemv_config<8, 4, 4, 2, true>>("w8 wpr4 r4 u2 nt", m, xv, rv));
-    entries.push_back(make<gemv_config<8, 8, 4, 2, true>>("w8 wpr8 r4 u2 nt (default)", m, xv, rv));
+    std::vector<entry> entries;
+#define ADD(W, WPR, R, U) \
+    entries.push_back(make<gemv_config<W, WPR, R, U, true>>("w" #W " wpr" #WPR " r" #R " u" #U " nt", m, xv, rv));
+    ADD(8, 8, 4, 2)
+    ADD(8, 8, 1, 8)
+    ADD(8, 8, 1, 16)
+    ADD(8, 8, 2, 4)
+    ADD(8, 8, 2, 8)
+    ADD(8, 8, 4, 1)
+    ADD(8, 8, 4, 3)
+    ADD(8, 8, 8, 2)
+    ADD(8, 4, 4, 2)
+    ADD(8, 4, 2, 4)
+    ADD(8, 4, 8, 1)
+    ADD(8, 2, 4, 2)
+    ADD(8, 2, 8, 1)
+    ADD(8, 1, 4, 2)
+    ADD(8, 1, 8, 1)
+    ADD(4, 4, 4, 2)
+    ADD(4, 4, 2, 4)
+    ADD(4, 4, 8, 2)
+    ADD(4, 2, 4, 2)
+    ADD(4, 1, 8, 1)
+    ADD(16, 16, 2, 2)
+    ADD(16, 8, 4, 2)
+    ADD(16, 4, 4, 2)
+    ADD(8, 8, 4, 2)
+#undef ADD
     hipEvent_t start, stop;
     CHECK(hipEventCreate(&start));
     CHECK(hipEventCreate(&stop));
