@@ -2,11 +2,45 @@
 // reference launchers do (`/root/reference/cuda/trsv_kernels.cuh:455-488`
 // plain, `:918-961` accessor).
 #include <array>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
 
 #include "accblas_trsv_common.hpp"
+
+
+namespace {
+std::atomic<int> trsv_split_option{0};
+}
+
+bool accblas::trsv_split_enabled() { return trsv_split_option.load() != 0; }
+
+extern "C" int accblas_set_option(const char *name, int value)
+{
+    if (name != nullptr && std::string(name) == "trsv_split") {
+        trsv_split_option.store(value);
+        return ACCBLAS_OK;
+    }
+    return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
+                              "accblas_set_option: unknown option");
+}
+
+int accblas::trsv_num_cus()
+{
+    static int cached = 0;
+    if (cached == 0) {
+        int device = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&device) == hipSuccess &&
+            hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            cached = prop.multiProcessorCount;
+        } else {
+            cached = 1;
+        }
+    }
+    return cached;
+}
 
 
 namespace {
@@ -122,18 +156,9 @@ int accblas_trsv(accblas_dtype vt, accblas_uplo uplo, accblas_diag diag,
             static_cast<const value_type *>(A), {n, n}, lda};
         const plain_view<value_type> x_view{static_cast<value_type *>(x),
                                             {n, 1}, incx};
-        granule_word *granules = nullptr;
-        const int ws_status =
-            accblas::trsv_get_workspace(accblas::as_stream(stream),
-                          trsv_workspace_bytes<value_type>(n), &granules);
-        if (ws_status != ACCBLAS_OK) {
-            return ws_status;
-        }
-        return accblas::check_hip(
-            launch_trsv<value_type>(uplo == ACCBLAS_UPPER, diag == ACCBLAS_UNIT,
-                                    m_view, x_view, helper, granules,
-                                    accblas::as_stream(stream)),
-            "trsv launch");
+        return accblas::trsv_dispatch<value_type, value_type>(
+            uplo == ACCBLAS_UPPER, diag == ACCBLAS_UNIT, n, m_view, x_view,
+            helper, stream);
     });
 }
 

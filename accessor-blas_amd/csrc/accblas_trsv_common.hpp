@@ -10,6 +10,7 @@
 
 #include "accblas_internal.hpp"
 #include "trsv_kernels.hpp"
+#include "trsv_split_kernels.hpp"
 
 
 namespace accblas {
@@ -19,6 +20,47 @@ namespace accblas {
  *  stream); defined in accblas_trsv.hip. */
 int trsv_get_workspace(hipStream_t stream, std::size_t bytes,
                        dev::granule_word **out);
+
+/** Compute units of the current device (cached). */
+int trsv_num_cus();
+
+/** Option "trsv_split" (accblas_set_option). */
+bool trsv_split_enabled();
+
+
+/** Picks the role-split kernel for large aligned systems, `kernel::trsv`
+ *  otherwise, and launches. */
+template <typename ar_type, typename st_type, typename MtxView, typename XView>
+int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
+                  const XView &x, uint32_t *helper, void *stream)
+{
+    dev::granule_word *granules = nullptr;
+    const std::size_t bytes =
+        std::max(dev::trsv_workspace_bytes<st_type>(n),
+                 dev::trsv_split_workspace_bytes<ar_type, st_type>(n));
+    const int ws_status = trsv_get_workspace(as_stream(stream), bytes, &granules);
+    if (ws_status != ACCBLAS_OK) {
+        return ws_status;
+    }
+    bool launched = false;
+    if (!trsv_split_enabled()) {
+        return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x,
+                                                   helper, granules,
+                                                   as_stream(stream)),
+                         "trsv launch");
+    }
+    const int split_status = check_hip(
+        dev::try_launch_trsv_split<ar_type>(upper, unit_diag, mtx, x, helper,
+                                            granules, trsv_num_cus(),
+                                            as_stream(stream), &launched),
+        "trsv (split) launch");
+    if (split_status != ACCBLAS_OK || launched) {
+        return split_status;
+    }
+    return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x, helper,
+                                               granules, as_stream(stream)),
+                     "trsv launch");
+}
 
 /** acc_trsv for one arithmetic type, all storage types. */
 int acc_trsv_f32(accblas_dtype st, accblas_uplo uplo, accblas_diag diag,
@@ -49,18 +91,9 @@ int acc_trsv_typed(accblas_dtype st, accblas_uplo uplo, accblas_diag diag,
                     stride_array{{lda}});
         const auto x_acc = range(size_array{{n, 1}}, static_cast<st_type *>(x),
                                  stride_array{{incx}});
-        dev::granule_word *granules = nullptr;
-        const int ws_status = trsv_get_workspace(
-            as_stream(stream), dev::trsv_workspace_bytes<st_type>(n),
-            &granules);
-        if (ws_status != ACCBLAS_OK) {
-            return ws_status;
-        }
-        return check_hip(
-            dev::launch_trsv<ar_type>(uplo == ACCBLAS_UPPER,
-                                      diag == ACCBLAS_UNIT, m_acc, x_acc,
-                                      helper, granules, as_stream(stream)),
-            "acc_trsv launch");
+        return trsv_dispatch<ar_type, st_type>(uplo == ACCBLAS_UPPER,
+                                               diag == ACCBLAS_UNIT, n, m_acc,
+                                               x_acc, helper, stream);
     });
 }
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     "accblas_last_error_string": (ctypes.c_char_p, []),
     "accblas_version": (_int, []),
     "accblas_dtype_size": (ctypes.c_size_t, [_int]),
+    "accblas_set_option": (_int, [ctypes.c_char_p, _int]),
     "accblas_device_count": (_int, [ctypes.POINTER(_int)]),
     "accblas_set_device": (_int, [_int]),
     "accblas_get_device": (_int, [ctypes.POINTER(_int)]),
@@ -147,6 +148,11 @@ def _stream(stream):
 
 def version():
     return load().accblas_version()
+
+
+def set_option(name, value):
+    """Tuning knobs of include/accblas.h (`accblas_set_option`)."""
+    _check(load().accblas_set_option(name.encode(), int(value)))
 
 
 def device_info(device=0):

@@ -73,6 +73,14 @@ const char *accblas_last_error_string(void);
 int accblas_version(void);
 size_t accblas_dtype_size(accblas_dtype t);
 
+/* Tuning knobs (no counterpart in the reference, whose choices are
+ * compile-time constants). Known names:
+ *   "trsv_split"  0 (default) = one workgroup per row block streams and
+ *                 solves (`kernel::trsv`); 1 = large aligned systems use the
+ *                 role-split kernel (persistent streamers + solvers).
+ * Unknown names return ACCBLAS_ERR_INVALID_ARGUMENT. */
+int accblas_set_option(const char *name, int value);
+
 /* ---- device / runtime (replaces cuda/utils.cuh:80-107, memory.cuh) ------ */
 int accblas_device_count(int *count);
 int accblas_set_device(int device);
