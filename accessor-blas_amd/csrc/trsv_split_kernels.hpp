@@ -14,15 +14,17 @@
 //     blocks {s, s+G, s+2G, ...} (cyclic => balanced at every moment), keeps
 //     their partial sums in registers and walks the column panels c = 0, 1, ...
 //     in order: as soon as x_c is published it applies panel (b, c) for every
-//     owned block b >= c + 2 (16-byte loads, double-buffered one panel ahead),
-//     and when block b has received its last far panel (c = b - 2) it reduces
+//     owned block b >= c + 3 (16-byte loads, double-buffered one panel ahead),
+//     and when block b has received its last far panel (c = b - 3) it reduces
 //     and publishes the 64 far corrections of b as granules. Streamers are
 //     persistent, hence resident for the whole solve: bandwidth is used from
 //     the first hop on, by all CUs.
 //   * every later workgroup is the SOLVER of one row block (ticket order =
-//     row order, as in the reference): it stages the diagonal tile and the
-//     last panel, inverts, folds (M = inv(T) A_{b,b-1}), then waits for its
-//     far corrections and for x_{b-1}, and publishes x_b. It streams nothing.
+//     row order, as in the reference): it stages the diagonal tile and the TWO
+//     panels next to it, inverts, folds (M2 = inv(T) A_{b,b-2} in registers,
+//     M1 = inv(T) A_{b,b-1} in LDS), then waits for its far corrections and
+//     x_{b-2} (both known at least one hop early), then for x_{b-1}, and
+//     publishes x_b. It streams nothing.
 // A workgroup only ever waits on workgroups that hold an earlier ticket
 // (streamers hold the first G; solver b waits on streamer (b mod G) and on
 // solver b-1), so the scheme is deadlock-free as long as at least G + 1
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(trsv_split_waves *wave_size, 2) void trsv_split(
     __shared__ ar_type partial_a[Waves * B];
     __shared__ ar_type partial_b[Waves * B];
     __shared__ ar_type x_prev_lds[B];
+    __shared__ ar_type x_prev2_lds[B];
     __shared__ std::int32_t shared_ticket;
 
     const int lane = lane_id();
@@ -110,20 +113,21 @@ __global__ __launch_bounds__(trsv_split_waves *wave_size, 2) void trsv_split(
         const index_type first = ticket;
         const int row_in_inst = lane / LPR;
         const int col_group = lane % LPR;
-        // owned blocks first + o * G; only blocks >= 2 have far panels
+        // owned blocks first + o * G; only blocks >= 3 have far panels (the
+        // solver itself applies the two panels next to the diagonal)
         index_type block_of[MO];
         index_type last_owned = -1;
 #pragma unroll
         for (int o = 0; o < MO; ++o) {
             block_of[o] = first + index_type{o} * num_streamers;
-            if (block_of[o] < num_blocks && block_of[o] >= 2) {
+            if (block_of[o] < num_blocks && block_of[o] >= 3) {
                 last_owned = block_of[o];
             }
         }
         if (last_owned < 0) {
             return;
         }
-        const index_type panel_end = last_owned - 1;  // panels [0, b_max - 2]
+        const index_type panel_end = last_owned - 2;  // panels [0, b_max - 3]
         ar_type acc[MO][NI];
 #pragma unroll
         for (int o = 0; o < MO; ++o) {
@@ -136,9 +140,9 @@ __global__ __launch_bounds__(trsv_split_waves *wave_size, 2) void trsv_split(
             st_type a[MO][NI][Vec];
             granule_word xraw[Vec][x_io::words];
         };
-        // block o takes part in panel c iff it exists and c <= block - 2
+        // block o takes part in panel c iff it exists and c <= block - 3
         const auto active = [&](int o, index_type c) {
-            return block_of[o] < num_blocks && block_of[o] >= c + 2;
+            return block_of[o] < num_blocks && block_of[o] >= c + 3;
         };
         const auto issue = [&](index_type c, stage &s) {
             const index_type first_col = c * B + col_group * Vec;  // logical
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(trsv_split_waves *wave_size, 2) void trsv_split(
                                          xv[Upper ? Vec - 1 - e : e];
                         }
                     }
-                    if (block_of[o] == c + 2) {
+                    if (block_of[o] == c + 3) {
                         // last far panel of this block: publish corrections
 #pragma unroll
                         for (int k = 0; k < NI; ++k) {
@@ -251,7 +255,18 @@ __global__ __launch_bounds__(trsv_split_waves *wave_size, 2) void trsv_split(
         own_rhs = static_cast<ar_type>(*own_addr);
     }
 
-    // diagonal tile and last panel -> LDS
+    // stages the 64 x 64 panel of logical block column `cb` into `panel`
+    // (column-major) and the diagonal tile into `tile` (row-major) if asked
+    const auto stage_panel = [&](index_type cb) {
+        for (int r = wave; r < B; r += Waves) {
+            const index_type gr = base + r;
+            ar_type off{};
+            if (gr < n) {
+                off = mtx(phys(gr), phys(cb * B + lane));
+            }
+            panel[lane * ld + r] = off;
+        }
+    };
     for (int r = wave; r < B; r += Waves) {
         const index_type gr = base + r;
         const index_type gc = base + lane;
@@ -263,13 +278,9 @@ __global__ __launch_bounds__(trsv_split_waves *wave_size, 2) void trsv_split(
             value = mtx(phys(gr), phys(gc));
         }
         tile[r * ld + lane] = value;
-        if (block > 0) {
-            ar_type off{};
-            if (gr < n) {
-                off = mtx(phys(gr), phys(base - B + lane));
-            }
-            panel[lane * ld + r] = off;
-        }
+    }
+    if (block >= 2) {
+        stage_panel(block - 2);
     }
     __syncthreads();
 
@@ -297,7 +308,17 @@ __global__ __launch_bounds__(trsv_split_waves *wave_size, 2) void trsv_split(
     }
     __syncthreads();
 
-    // fold: M = inv(T_bb) * A_{b,b-1}, CW columns per wave, in place
+    // fold the inverse into the two panels next to the diagonal:
+    //   x_b = inv(T) (rhs_far) - M2 x_{b-2} - M1 x_{b-1},
+    //   M2 = inv(T) A_{b,b-2} kept in REGISTERS (CW entries of this thread's
+    //   row), M1 = inv(T) A_{b,b-1} kept in LDS in place of the panel.
+    // Two near panels give the streamers two hops of lead for the far
+    // corrections, which keeps their hand-off off the chain's 2-hop path.
+    ar_type m2[CW];
+#pragma unroll
+    for (int j = 0; j < CW; ++j) {
+        m2[j] = ar_type{};
+    }
     if (block > 0) {
         ar_type inv_row[B];
 #pragma unroll
@@ -305,6 +326,22 @@ __global__ __launch_bounds__(trsv_split_waves *wave_size, 2) void trsv_split(
             inv_row[k] = tile[k * ld + lane];
         }
         constexpr int CG = 4;
+        if (block >= 2) {
+#pragma unroll
+            for (int c0 = 0; c0 < CW; c0 += CG) {
+                const int col = wave_u * CW + c0;
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+#pragma unroll
+                    for (int q = 0; q < CG; ++q) {
+                        m2[c0 + q] += inv_row[k] * panel[(col + q) * ld + k];
+                    }
+                }
+            }
+            __syncthreads();  // every wave is done reading panel b-2
+        }
+        stage_panel(block - 1);
+        __syncthreads();
         for (int c0 = 0; c0 < CW; c0 += CG) {
             const int col = wave_u * CW + c0;
             ar_type m[CG];
@@ -326,9 +363,12 @@ __global__ __launch_bounds__(trsv_split_waves *wave_size, 2) void trsv_split(
         }
     }
 
-    // far corrections from this block's streamer (blocks 0 and 1 have none)
-    if (block >= 2) {
-        if (wave == 0) {
+    // far corrections from this block's streamer (blocks 0..2 have none) are
+    // polled by wave 1, x_{b-2} by wave 0; both arrive at least one hop
+    // before x_{b-1}
+    if (wave == 1) {
+        ar_type far{};
+        if (block >= 3) {
             granule_word raw[c_io::words];
             c_io::load(corr_granules, base + lane, raw);
             while (!__all(c_io::ready(raw)) &&
@@ -336,14 +376,24 @@ __global__ __launch_bounds__(trsv_split_waves *wave_size, 2) void trsv_split(
                 __builtin_amdgcn_s_sleep(1);
                 c_io::load(corr_granules, base + lane, raw);
             }
-            correction[lane] = c_io::decode(raw);
+            far = c_io::decode(raw);
         }
-    } else if (wave == 0) {
-        correction[lane] = ar_type{};
+        correction[lane] = far;
+    }
+    if (wave == 0 && block >= 2) {
+        granule_word raw[x_io::words];
+        const index_type prev2 = base - 2 * B + lane;
+        x_io::load(x_granules, prev2, raw);
+        while (!__all(x_io::ready(raw)) &&
+               !detail::spin_expired(spins, helper)) {
+            __builtin_amdgcn_s_sleep(1);
+            x_io::load(x_granules, prev2, raw);
+        }
+        x_prev2_lds[lane] = static_cast<ar_type>(x_io::decode(raw));
     }
     __syncthreads();
 
-    // c = inv(T) rhs_far (before the wait for x_{b-1})
+    // c = inv(T) rhs_far - M2 x_{b-2} (before the wait for x_{b-1})
     ar_type rhs = own_valid ? own_rhs - correction[lane] : ar_type{};
     {
         ar_type part[2] = {};
@@ -351,6 +401,12 @@ __global__ __launch_bounds__(trsv_split_waves *wave_size, 2) void trsv_split(
         for (int j = 0; j < CW; ++j) {
             part[j & 1] += tile[(wave_u * CW + j) * ld + lane] *
                            detail::read_lane(rhs, wave_u * CW + j);
+        }
+        if (block >= 2) {
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+                part[j & 1] -= m2[j] * x_prev2_lds[wave_u * CW + j];
+            }
         }
         partial_b[wave_u * B + lane] = part[0] + part[1];
     }
