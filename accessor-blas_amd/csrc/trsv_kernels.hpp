@@ -162,6 +162,27 @@ __device__ __forceinline__ T read_lane(T value, int src_lane)
     return out;
 }
 
+/** sum_{w < Count} values[w * stride + lane], combined as a balanced tree
+ *  (fixed order, so the result is reproducible). */
+template <int Count, typename T>
+__device__ __forceinline__ T tree_sum(const T *values, int stride, int lane)
+{
+    static_assert(Count >= 1 && (Count & (Count - 1)) == 0, "power of two");
+    T level[Count];
+#pragma unroll
+    for (int w = 0; w < Count; ++w) {
+        level[w] = values[w * stride + lane];
+    }
+#pragma unroll
+    for (int width = Count / 2; width >= 1; width /= 2) {
+#pragma unroll
+        for (int w = 0; w < width; ++w) {
+            level[w] = level[2 * w] + level[2 * w + 1];
+        }
+    }
+    return level[0];
+}
+
 /** Encoding of one storage element into 1 (<= 4 bytes) or 2 (8 bytes)
  *  granules: low 32 bits payload, high 32 bits tag. */
 template <typename St>
@@ -538,13 +559,14 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     {
         // every wave holds the full right-hand side (lane = row); entry
         // wave*CW + j of it multiplies column wave*CW + j of the inverse
-        ar_type part[2] = {};
+        ar_type part[4] = {};
 #pragma unroll
         for (int j = 0; j < CW; ++j) {
-            part[j & 1] += tile[(wave_u * CW + j) * ld + lane] *
+            part[j & 3] += tile[(wave_u * CW + j) * ld + lane] *
                            detail::read_lane(rhs, wave_u * CW + j);
         }
-        partial_b[wave_u * B + lane] = part[0] + part[1];
+        partial_b[wave_u * B + lane] =
+            (part[0] + part[1]) + (part[2] + part[3]);
     }
     if (block > 0) {
         // critical path starts here. ONE wave polls the 64 granules of
@@ -567,13 +589,14 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
         if (wave == 0) {
             ACCBLAS_TRSV_STAMP(block, 7);  // x_{b-1} handed to all waves
         }
-        ar_type part[2] = {};
+        ar_type part[4] = {};
 #pragma unroll
         for (int j = 0; j < CW; ++j) {
-            part[j & 1] += panel[(wave_u * CW + j) * ld + lane] *
+            part[j & 3] += panel[(wave_u * CW + j) * ld + lane] *
                            x_prev_lds[wave_u * CW + j];
         }
-        partial_a[wave_u * B + lane] = part[0] + part[1];
+        partial_a[wave_u * B + lane] =
+            (part[0] + part[1]) + (part[2] + part[3]);
         if (wave == 0) {
             ACCBLAS_TRSV_STAMP(block, 8);  // wave 0 mat-vec share done
         }
@@ -581,18 +604,10 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     __syncthreads();
     if (wave == 0) {
         ACCBLAS_TRSV_STAMP(block, 9);  // all mat-vec shares done
-        ar_type sum = partial_b[lane];
-#pragma unroll
-        for (int w = 1; w < Waves; ++w) {
-            sum += partial_b[w * B + lane];
-        }
+        // balanced trees: a dependent fp64 add costs ~32 cycles on gfx950
+        ar_type sum = detail::tree_sum<Waves>(partial_b, B, lane);
         if (block > 0) {
-            ar_type fold = partial_a[lane];
-#pragma unroll
-            for (int w = 1; w < Waves; ++w) {
-                fold += partial_a[w * B + lane];
-            }
-            sum -= fold;
+            sum -= detail::tree_sum<Waves>(partial_a, B, lane);
         }
         const st_type solution = static_cast<st_type>(sum);
         if (own_valid) {
