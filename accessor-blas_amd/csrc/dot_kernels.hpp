@@ -56,7 +56,7 @@ struct dot_config {
  *  5.0 TB/s at 2 x 64 MiB). */
 using dot_stride_config = dot_config<8, 4, 2, false>;
 using dot_contiguous_config = dot_config<8, 4, 2, true>;
-constexpr index_type dot_contiguous_min_bytes = index_type{1} << 29;
+constexpr index_type dot_contiguous_min_bytes = index_type{1} << 27;
 struct dot_auto_config {};
 
 
@@ -126,13 +126,16 @@ __global__ __launch_bounds__(Config::waves *wave_size) void dot(
         const st_type *x_ptr = x_traits::data(x);
         const st_type *y_ptr = y_traits::data(y);
         const index_type all_chunks = n / Vec;
-        const index_type per_block = ceildiv(all_chunks, gridDim.x);
+        // slices start on 4 KiB boundaries (256 chunks of 16 bytes)
+        const index_type per_block =
+            ceildiv(ceildiv(all_chunks, gridDim.x), 256) * 256;
         const index_type first =
             Config::contiguous ? index_type{blockIdx.x} * per_block : 0;
         const index_type num_chunks =
             Config::contiguous
-                ? (first + per_block < all_chunks ? first + per_block
-                                                  : all_chunks)
+                ? (first + per_block < all_chunks
+                       ? first + per_block
+                       : (first < all_chunks ? all_chunks : first))
                 : all_chunks;
         index_type chunk = Config::contiguous ? first + threadIdx.x : tid;
         // Unroll independent chunk pairs per lane per iteration
