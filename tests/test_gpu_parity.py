@@ -379,3 +379,26 @@ def test_trsv_workspace_grows_and_helper_reports_no_timeout(gpu):
         torch.cuda.synchronize()
         assert int(helper[0].item()) & 0xffffffff == 0xffffffff
         assert oracle.rel_error(want, dx.cpu().numpy()) <= 1e-11
+
+
+@pytest.mark.parametrize("src,dst", [(F64, F32), (F64, F16), (F32, F16), (F16, F64),
+                                     (F32, F64), (F16, F32)])
+def test_device_convert_is_the_reference_static_cast(gpu, src, dst):
+    """`accblas_convert` (convert_mtx with static_cast, matrix_helper.cuh:91-103,
+    done in HBM) rounds exactly like the host conversion: single rounding, RNE,
+    incl. fp16 subnormals, ties and overflow to infinity."""
+    torch, accblas = gpu
+    rng = np.random.default_rng(60)
+    values = np.concatenate([rng.uniform(-1, 1, 20000), rng.uniform(-70000, 70000, 2000),
+                             rng.uniform(-1e-7, 1e-7, 2000), 2.0 ** np.arange(-30, 17),
+                             [0.0, -0.0, 65504.0, 65519.99, 65520.0, 2.0 ** -25,
+                              2.0 ** -25 * (1 + 2.0 ** -30), 1 + 2.0 ** -11, 1 + 3 * 2.0 ** -11]])
+    host_src = oracle.convert(values, src)
+    want = oracle.convert(host_src, dst)
+    d_src = to_dev(torch, host_src)
+    d_dst = torch.empty(host_src.size, dtype=accblas.torch_dtype(dst), device="cuda")
+    accblas.convert(dst, d_dst, src, d_src, host_src.size)
+    torch.cuda.synchronize()
+    got = d_dst.cpu().numpy()
+    bits = {F16: np.uint16, F32: np.uint32, F64: np.uint64}[dst]
+    assert np.array_equal(got.view(bits), want.view(bits))
