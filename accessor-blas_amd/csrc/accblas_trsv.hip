@@ -12,14 +12,20 @@
 
 namespace {
 std::atomic<int> trsv_split_option{0};
+std::atomic<int> trsv_wide_option{0};
 }
 
 bool accblas::trsv_split_enabled() { return trsv_split_option.load() != 0; }
+bool accblas::trsv_wide_enabled() { return trsv_wide_option.load() != 0; }
 
 extern "C" int accblas_set_option(const char *name, int value)
 {
     if (name != nullptr && std::string(name) == "trsv_split") {
         trsv_split_option.store(value);
+        return ACCBLAS_OK;
+    }
+    if (name != nullptr && std::string(name) == "trsv_wide") {
+        trsv_wide_option.store(value);
         return ACCBLAS_OK;
     }
     return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,

@@ -11,6 +11,7 @@
 #include "accblas_internal.hpp"
 #include "trsv_kernels.hpp"
 #include "trsv_split_kernels.hpp"
+#include "trsv_wide_kernels.hpp"
 
 
 namespace accblas {
@@ -24,8 +25,9 @@ int trsv_get_workspace(hipStream_t stream, std::size_t bytes,
 /** Compute units of the current device (cached). */
 int trsv_num_cus();
 
-/** Option "trsv_split" (accblas_set_option). */
+/** Options "trsv_split" / "trsv_wide" (accblas_set_option). */
 bool trsv_split_enabled();
+bool trsv_wide_enabled();
 
 
 /** Picks the role-split kernel for large aligned systems, `kernel::trsv`
@@ -43,6 +45,16 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
         return ws_status;
     }
     bool launched = false;
+    if (trsv_wide_enabled()) {
+        const int wide_status = check_hip(
+            dev::try_launch_trsv_wide<ar_type>(upper, unit_diag, mtx, x, helper,
+                                               granules, as_stream(stream),
+                                               &launched),
+            "trsv (128-row) launch");
+        if (wide_status != ACCBLAS_OK || launched) {
+            return wide_status;
+        }
+    }
     if (!trsv_split_enabled()) {
         return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x,
                                                    helper, granules,

@@ -78,6 +78,9 @@ size_t accblas_dtype_size(accblas_dtype t);
  *   "trsv_split"  0 (default) = one workgroup per row block streams and
  *                 solves (`kernel::trsv`); 1 = large aligned systems use the
  *                 role-split kernel (persistent streamers + solvers).
+ *   "trsv_wide"   0 (default) / 1 = systems with n >= 4096 and 2- or 4-byte
+ *                 storage use 128-row blocks (`kernel::trsv_wide`): half as many
+ *                 dependent hops, the folded panel held in registers.
  * Unknown names return ACCBLAS_ERR_INVALID_ARGUMENT. */
 int accblas_set_option(const char *name, int value);
 

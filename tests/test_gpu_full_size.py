@@ -186,15 +186,17 @@ def test_trsv_24000_matches_reference_shape_both_paths(gpu):
     assert rel_l1(torch, x_vec, x_scalar) <= 1e-6
 
 
+@pytest.mark.parametrize("option", ["trsv_split", "trsv_wide"])
 @pytest.mark.parametrize("upper", [False, True])
 @pytest.mark.parametrize("unit", [True, False])
 @pytest.mark.parametrize("ar,st", [(F64, F32), (F32, F32), (F32, F16)])
-def test_trsv_role_split_kernel_matches_oracle(gpu, upper, unit, ar, st):
-    """n = 12300 (>= the split threshold, ragged last block, lda > n) goes through the
-    role-split kernel (persistent streamers + per-block solvers); compared with the
-    semantic oracle on the same storage-rounded data."""
+def test_trsv_alternative_kernels_match_oracle(gpu, option, upper, unit, ar, st):
+    """n = 12300 (ragged last block, lda > n) through the opt-in kernels: the
+    role-split one (persistent streamers + per-block solvers) and the 128-row one
+    (inverse and folded panel distributed over the workgroup's registers); compared
+    with the semantic oracle on the same storage-rounded data."""
     torch, accblas = gpu
-    accblas.set_option("trsv_split", 1)
+    accblas.set_option(option, 1)
     n, lda = 12300, 12304
     rng = np.random.default_rng(77)
     full = rng.uniform(-1.0, 1.0, (n, lda)) / np.sqrt(n)
@@ -218,5 +220,5 @@ def test_trsv_role_split_kernel_matches_oracle(gpu, upper, unit, ar, st):
     accblas.acc_trsv(ar, st, accblas.UPPER if upper else accblas.LOWER,
                      accblas.UNIT if unit else accblas.NON_UNIT, n, dA, lda, dx2, 1, helper)
     torch.cuda.synchronize()
-    accblas.set_option("trsv_split", 0)
+    accblas.set_option(option, 0)
     assert torch.equal(dx, dx2)

@@ -84,6 +84,9 @@ def trsv(n, ar, st, upper, unit=True):
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     print(accblas.device_info(0), flush=True)
+    if os.environ.get("ACCBLAS_TRSV_WIDE") == "1":
+        accblas.set_option("trsv_wide", 1)
+        print("trsv_wide = 1", flush=True)
     if os.environ.get("ACCBLAS_TRSV_SPLIT") == "1":
         accblas.set_option("trsv_split", 1)
         print("trsv_split = 1", flush=True)
