@@ -27,6 +27,8 @@ def pytest_sessionstart(session):
     pkg = os.path.join(REPO, "accessor-blas_amd")
     wanted = [os.path.join(pkg, "lib", "libaccblas_hip.so"),
               os.path.join(pkg, "lib", "libaccblas_vendor.so"),
+              os.path.join(pkg, "lib", "libaccblas_rccl.so"),
+              os.path.join(pkg, "bin", "multi_gpu_benchmark"),
               os.path.join(pkg, "bin", "gemv_benchmark")]
     if not all(os.path.exists(p) for p in wanted):
         subprocess.run(["make", "-C", pkg, "-j", str(min(8, os.cpu_count() or 1)), "all"],

@@ -82,3 +82,57 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(accblas, "LIB_PATH", "/nonexistent/libaccblas_hip.so")
     with pytest.raises(FileNotFoundError, match="no CPU fallback"):
         accblas.load()
+
+
+# ---- the other two boundary headers ------------------------------------------
+
+def header_symbols(name):
+    text = open(os.path.join(REPO, "include", name)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(accblas_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported_symbols(library):
+    out = subprocess.run(["nm", "-D", "--defined-only", library], check=True,
+                         capture_output=True, text=True).stdout
+    return set(re.findall(r"\bT (accblas_[a-z0-9_]+)\b", out))
+
+
+@pytest.mark.parametrize("header, library", [
+    ("accblas_vendor.h", "libaccblas_vendor.so"),
+    ("accblas_comm.h", "libaccblas_rccl.so"),
+])
+def test_side_libraries_export_their_headers(header, library):
+    names = header_symbols(header)
+    assert names, header
+    path = os.path.join(accblas.PACKAGE_ROOT, "lib", library)
+    assert exported_symbols(path) == set(names)
+
+
+def test_comm_prototypes_and_host_side_validation():
+    from accblas import comm, multi_gpu
+    lib = comm.load_comm()
+    assert sorted(comm.SIGNATURES) == header_symbols("accblas_comm.h")
+    # the partition is the one the torch.distributed layer uses
+    for n, world in [(0, 1), (10, 3), (7, 8), (1 << 28, 8), (32768, 6)]:
+        pieces = [comm.shard_bounds(n, world, r) for r in range(world)]
+        assert pieces == [multi_gpu.shard_bounds(n, world, r) for r in range(world)]
+    # aligned boundaries still tile [0, n) and interior edges are multiples of 8
+    pieces = [comm.shard_bounds(1000003, 8, r, 8) for r in range(8)]
+    assert pieces[0][0] == 0 and pieces[-1][1] == 1000003
+    assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+    assert all(p[1] % 8 == 0 for p in pieces[:-1])
+    # validation happens before RCCL / HIP are touched
+    dummy = ctypes.c_void_p(0x1000)
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    assert lib.accblas_shard_bounds(10, 0, 0, 1, ctypes.byref(lo), ctypes.byref(hi)) == -2
+    assert lib.accblas_shard_bounds(10, 2, 2, 1, ctypes.byref(lo), ctypes.byref(hi)) == -2
+    assert lib.accblas_comm_create(None, 1, 0, dummy) == -3
+    raw = ctypes.c_void_p()
+    assert lib.accblas_comm_create(ctypes.byref(raw), 2, 2, dummy) == -2
+    assert b"rank" in lib.accblas_comm_last_error_string()
+    assert lib.accblas_comm_acc_dot(None, None, 1, 0, 1, 8, dummy, 1, dummy, 1, dummy,
+                                    None) == -3
+    assert lib.accblas_comm_acc_gemv(None, 2, 1, 4, 4, 1.0, dummy, 4, dummy, 1, 0.0,
+                                     dummy, 1, None, None) == -3
+    assert lib.accblas_comm_destroy(None) == 0

@@ -1,0 +1,105 @@
+"""C-level multi-GPU context (include/accblas_comm.h) on the one GPU of the test
+box: a world of one rank exercises communicator creation (both ways), the
+sharded entry points and the driver binary; with one rank the results must equal
+the single-GPU entry points bit for bit. More ranks run on the 8-GPU node only
+(`bin/multi_gpu_benchmark --gpus=8`, `bench.py --gpus 8`)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import accblas
+from accblas import comm
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def handle():
+    h = accblas.Handle()
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="module", params=["unique_id", "create_all"])
+def world_of_one(request):
+    torch.cuda.set_device(0)
+    if request.param == "unique_id":
+        c = comm.Comm.create(1, 0, comm.unique_id())
+    else:
+        (c,) = comm.Comm.create_all(1)
+    assert (c.rank, c.world_size, c.device) == (0, 1, 0)
+    yield c
+    c.close()
+
+
+def test_comm_dot_equals_single_gpu_dot(world_of_one, handle):
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    n = 3_000_001
+    x = (torch.rand(n, generator=gen, dtype=torch.float64) * 2 - 1).to(torch.float16).to(DEV)
+    y = (torch.rand(n, generator=gen, dtype=torch.float64) * 2 - 1).to(torch.float16).to(DEV)
+    lo, hi = world_of_one.shard(n, 8)
+    assert (lo, hi) == (0, n)
+    single = torch.zeros(1, dtype=torch.float32, device=DEV)
+    accblas.acc_dot(handle, accblas.F32, accblas.F16, accblas.F32, n, x, 1, y, 1, single)
+    for res_dtype, res_t in [(torch.float32, accblas.F32), (torch.float64, accblas.F64)]:
+        res = torch.full((1,), 7.0, dtype=res_dtype, device=DEV)
+        world_of_one.acc_dot(handle, accblas.F32, accblas.F16, res_t, n, x, 1, y, 1, res)
+        torch.cuda.synchronize()
+        assert res.item() == single.item()  # cast after the exchange: exact widening
+    # an empty chunk contributes zero
+    res = torch.full((1,), 7.0, dtype=torch.float32, device=DEV)
+    world_of_one.acc_dot(handle, accblas.F32, accblas.F16, accblas.F32, 0, x, 1, y, 1, res)
+    torch.cuda.synchronize()
+    assert res.item() == 0.0
+
+
+def test_comm_gemv_equals_single_gpu_gemv(world_of_one):
+    gen = torch.Generator(device="cpu").manual_seed(12)
+    rows, cols = 777, 2051
+    A = (torch.rand(rows, cols, generator=gen, dtype=torch.float64) * 2 - 1).float().to(DEV)
+    x = (torch.rand(cols, generator=gen, dtype=torch.float64) * 2 - 1).float().to(DEV)
+    init = (torch.rand(rows, generator=gen, dtype=torch.float64) * 2 - 1).float().to(DEV)
+    want = init.clone()
+    accblas.acc_gemv(accblas.F64, accblas.F32, rows, cols, 0.5, A, cols, x, 1, -1.0, want, 1)
+    local = init.clone()
+    full = torch.zeros(rows, dtype=torch.float32, device=DEV)
+    world_of_one.acc_gemv(accblas.F64, accblas.F32, rows, cols, 0.5, A, cols, x, 1, -1.0,
+                          local, 1, res_full=full)
+    torch.cuda.synchronize()
+    assert torch.equal(local, want) and torch.equal(full, want)
+    # the gather needs a contiguous slice
+    with pytest.raises(accblas.AccblasError) as info:
+        world_of_one.acc_gemv(accblas.F64, accblas.F32, rows // 2, cols, 1.0, A, cols, x, 1,
+                              0.0, local, 2, res_full=full)
+    assert info.value.status == -2
+
+
+def test_comm_rejects_unsupported_arithmetic(world_of_one, handle):
+    x = torch.zeros(8, dtype=torch.float16, device=DEV)
+    res = torch.zeros(1, dtype=torch.float32, device=DEV)
+    with pytest.raises(accblas.AccblasError) as info:
+        world_of_one.acc_dot(handle, accblas.F16, accblas.F16, accblas.F32, 8, x, 1, x, 1, res)
+    assert info.value.status == -1
+
+
+def test_multi_gpu_driver_on_one_device():
+    exe = os.path.join(accblas.PACKAGE_ROOT, "bin", "multi_gpu_benchmark")
+    out = subprocess.run([exe, "--gpus=1", "--dot-size=5000001", "--gemv-size=2048",
+                          "--runs=3"], check=True, capture_output=True, text=True,
+                         timeout=300).stdout
+    lines = {l.split(";")[0]: dict(f.split("=") for f in l.strip().split(";")[1:])
+             for l in out.splitlines() if l.startswith(("DOT", "GEMV"))}
+    dot = lines["DOT Acc<fp32, fp16>"]
+    assert dot["all_ranks_identical"] == "yes" and dot["gpus"] == "1"
+    # fp32 accumulation in blocks: gate on the natural scale of the sum (the
+    # driver's repeated data block makes the sum itself large)
+    scale = max(np.sqrt(5000001) / 3, abs(float(dot["expected"])))
+    assert float(dot["abs_err"]) <= 64 * 2.0 ** -24 * scale
+    gemv = lines["GEMV Acc<fp64, fp32>"]
+    assert gemv["all_ranks_identical"] == "yes"
+    assert float(gemv["rel_err_sampled_rows"]) <= 1e-7
