@@ -14,8 +14,11 @@
 //   * values are widened to the arithmetic type in registers, FMA'd, reduced
 //     with a 6-step 64-lane shuffle; waves of a group combine through LDS
 //     (one value per wave and row), no barrier tree;
-//   * anything the vector path cannot take (unaligned base or row stride,
-//     incx != 1) goes through `gemv_generic`, which uses only `operator()`.
+//   * a strided or unaligned x keeps the 16-byte matrix loads and fetches x
+//     element-wise through `operator()` (VecX = false): x is L2-resident and
+//     1/R of the matrix traffic, the stream stays the bound;
+//   * anything the vector path cannot take (unaligned matrix base or row
+//     stride) goes through `gemv_generic`, which uses only `operator()`.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -46,17 +49,39 @@ struct gemv_config {
 namespace kernel {
 
 
+/** Vec consecutive x entries starting at column c, widened to ArType: one
+ *  16-byte load (VecX) or Vec accesses through the view (any increment). */
+template <bool VecX, int Vec, typename XView, typename StType, typename ArType>
+__device__ __forceinline__ void load_x(const XView &x, const StType *x_ptr,
+                                       index_type c, ArType (&out)[Vec])
+{
+    if constexpr (VecX) {
+        const auto xv = load_packed<Vec, false>(x_ptr + c);
+#pragma unroll
+        for (int k = 0; k < Vec; ++k) {
+            out[k] = static_cast<ArType>(xv[k]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < Vec; ++k) {
+            out[k] = x(c + k, 0);
+        }
+    }
+}
+
+
 /**
  * Vector-load GEMV. Requirements checked by the launcher: storage pointer of
- * mtx and x aligned to Vec*sizeof(St), row stride % Vec == 0, x increment 1.
+ * mtx aligned to Vec*sizeof(St), row stride % Vec == 0; with VecX also x
+ * aligned and of increment 1 (otherwise x goes through operator()).
  * res may have any increment (it is only touched through operator()).
  *
  * Follows `cuda/gemv_kernels.cuh:79-113` in meaning: local_result +=
  * mtx(row, col) * x(col, 0) in ArType, then
  * res(row,0) = alpha*sum (+ beta*res(row,0) if beta != 0).
  */
-template <typename Config, int Vec, typename ArType, typename MtxView,
-          typename XView, typename ResView>
+template <typename Config, int Vec, bool VecX, typename ArType,
+          typename MtxView, typename XView, typename ResView>
 __global__ __launch_bounds__(Config::waves *wave_size) void gemv_vec(
     ArType alpha, MtxView mtx, XView x, ArType beta, ResView res)
 {
@@ -105,12 +130,12 @@ __global__ __launch_bounds__(Config::waves *wave_size) void gemv_vec(
     const index_type lane_off =
         index_type{wave_in_group} * wave_cols + index_type{lane} * Vec;
     for (index_type c0 = 0; c0 < main_cols; c0 += iter_cols) {
-        typename packed<st_type, Vec>::type xv[U];
+        ar_type xa[U][Vec];
         typename packed<st_type, Vec>::type av[R][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const index_type c = c0 + index_type{u} * WPR * wave_cols + lane_off;
-            xv[u] = load_packed<Vec, false>(x_ptr + c);
+            load_x<VecX, Vec>(x, x_ptr, c, xa[u]);
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 av[j][u] = load_packed<Vec, Config::nt>(row_ptr[j] + c);
@@ -120,10 +145,9 @@ __global__ __launch_bounds__(Config::waves *wave_size) void gemv_vec(
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int k = 0; k < Vec; ++k) {
-                const ar_type xk = static_cast<ar_type>(xv[u][k]);
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    acc[j] += static_cast<ar_type>(av[j][u][k]) * xk;
+                    acc[j] += static_cast<ar_type>(av[j][u][k]) * xa[u][k];
                 }
             }
         }
@@ -133,14 +157,14 @@ __global__ __launch_bounds__(Config::waves *wave_size) void gemv_vec(
     for (index_type c = main_cols + lane_off; c < num_cols;
          c += WPR * wave_cols) {
         if (c + Vec <= num_cols) {
-            const auto xv = load_packed<Vec, false>(x_ptr + c);
+            ar_type xa[Vec];
+            load_x<VecX, Vec>(x, x_ptr, c, xa);
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 const auto av = load_packed<Vec, Config::nt>(row_ptr[j] + c);
 #pragma unroll
                 for (int k = 0; k < Vec; ++k) {
-                    acc[j] += static_cast<ar_type>(av[k]) *
-                              static_cast<ar_type>(xv[k]);
+                    acc[j] += static_cast<ar_type>(av[k]) * xa[k];
                 }
             }
         } else {
@@ -291,14 +315,22 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
     const dim3 block(Config::waves * wave_size, 1, 1);
     const dim3 grid(
         static_cast<unsigned>(ceildiv(rows, Config::rows_per_block)), 1, 1);
-    if (unit_x && lda % vec16 == 0 && is_aligned(a_ptr, 16) &&
-        is_aligned(x_ptr, 16)) {
-        kernel::gemv_vec<Config, vec16>
-            <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
-    } else if (vec8 > 1 && unit_x && lda % vec8 == 0 &&
-               is_aligned(a_ptr, 8) && is_aligned(x_ptr, 8)) {
-        kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2)>
-            <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+    if (lda % vec16 == 0 && is_aligned(a_ptr, 16)) {
+        if (unit_x && is_aligned(x_ptr, 16)) {
+            kernel::gemv_vec<Config, vec16, true>
+                <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+        } else {
+            kernel::gemv_vec<Config, vec16, false>
+                <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+        }
+    } else if (vec8 > 1 && lda % vec8 == 0 && is_aligned(a_ptr, 8)) {
+        if (unit_x && is_aligned(x_ptr, 8)) {
+            kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), true>
+                <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+        } else {
+            kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), false>
+                <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+        }
     } else {
         constexpr int waves = 4;
         kernel::gemv_generic<waves>

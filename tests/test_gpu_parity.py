@@ -147,6 +147,25 @@ def test_gemv_strided_vectors(gpu):
     assert err <= 1e-7
 
 
+@pytest.mark.parametrize("st,tol", [(F16, 1e-3), (F32, 1e-7), (F64, 1e-13)])
+@pytest.mark.parametrize("incx,x_offset", [(3, 0), (1, 1), (2, 1)])
+def test_gemv_vector_matrix_loads_with_strided_or_unaligned_x(gpu, st, tol, incx, x_offset):
+    """Aligned matrix, x strided and/or off the 16-byte grid: 16-byte matrix
+    loads + element-wise x (`gemv_vec<.., VecX = false>`); ragged cols and rows."""
+    torch, accblas = gpu
+    rows, cols, lda = 203, 4099, 4112
+    A = make_inputs(31, rows * lda, st)
+    x = make_inputs(32, cols * incx + x_offset, st)
+    res = make_inputs(33, rows, st)
+    want = oracle.exact_gemv(F64, rows, cols, 0.75, A, lda, x[x_offset:], incx, -0.5, res, 1)
+    dres = to_dev(torch, res)
+    accblas.acc_gemv(F64, st, rows, cols, 0.75, to_dev(torch, A), lda,
+                     to_dev(torch, x)[x_offset:], incx, -0.5, dres, 1)
+    torch.cuda.synchronize()
+    got = dres.cpu().numpy()
+    assert oracle.rel_error(want.astype(np.float64), got.astype(np.float64)) <= tol
+
+
 def test_gemv_empty_and_errors(gpu):
     torch, accblas = gpu
     dummy = torch.zeros(4, dtype=torch.float32, device="cuda")

@@ -32,6 +32,23 @@ def test_host_unit_tests(tmp_path):
     assert "host tests ok" in out.stdout
 
 
+def test_host_unit_tests_under_sanitizers(tmp_path):
+    """AddressSanitizer + UBSan on the CPU build (the GPU pool has no sanitizer
+    support): accessor indexing, Memory<T> ownership, float16 bit tricks."""
+    exe = tmp_path / "host_tests_san"
+    subprocess.run(
+        ["g++", "-std=c++14", "-O1", "-g", "-fsanitize=address,undefined",
+         "-fno-sanitize-recover=all",
+         os.path.join(REPO, "tests", "cpp", "host_tests.cpp"), "-o", str(exe),
+         "-I", os.path.join(PKG, "include"), "-I", os.path.join(REPO, "include"),
+         "-I", os.path.join(PKG, "hip"), "-L", os.path.join(PKG, "lib"), "-laccblas_hip",
+         "-Wl,-rpath," + os.path.join(PKG, "lib")], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host tests ok" in out.stdout
+
+
 def test_accessor_headers_compile_for_gfx950(tmp_path):
     """The same headers must compile as device code (hipcc cross-compiles)."""
     src = tmp_path / "dev.hip"

@@ -35,15 +35,15 @@ def rand(n, dt, scale=1.0):
     return t.to(accblas.torch_dtype(dt))
 
 
-def gemv(n, ar, st, plain=False):
-    A, x, r = rand(n * n, st), rand(n, st), rand(n, st)
+def gemv(n, ar, st, plain=False, incx=1):
+    A, x, r = rand(n * n, st), rand(n * incx, st), rand(n, st)
     if plain:
-        fn = lambda: accblas.gemv(st, n, n, 1.0, A, n, x, 1, 1.0, r, 1)
+        fn = lambda: accblas.gemv(st, n, n, 1.0, A, n, x, incx, 1.0, r, 1)
     else:
-        fn = lambda: accblas.acc_gemv(ar, st, n, n, 1.0, A, n, x, 1, 1.0, r, 1)
+        fn = lambda: accblas.acc_gemv(ar, st, n, n, 1.0, A, n, x, incx, 1.0, r, 1)
     ms = time_ms(fn)
     byts = SIZE[st] * (n * n + 3 * n)
-    print(f"GEMV n={n} {'plain ' + NAME[st] if plain else 'Acc<' + NAME[ar] + ',' + NAME[st] + '>'}"
+    print(f"GEMV n={n} incx={incx} {'plain ' + NAME[st] if plain else 'Acc<' + NAME[ar] + ',' + NAME[st] + '>'}"
           f": {ms * 1e3:9.1f} us  {byts / ms / 1e6:8.1f} GB/s  {2 * n * n / ms / 1e6:8.1f} GFLOP/s",
           flush=True)
 
@@ -98,6 +98,8 @@ if __name__ == "__main__":
         gemv(32768, F64, F16)
         gemv(32768, F32, F16)
         gemv(24500, F64, F32)
+        gemv(32768, F64, F32, incx=2)
+        gemv(32768, F64, F16, incx=3)
         gemv(4096, F64, F32)
         gemv(1024, F64, F32)
     if what in ("all", "dot"):
