@@ -52,31 +52,34 @@ int accblas::trsv_num_cus()
 namespace {
 
 
-// Hand-off workspace of the solve kernel (8-byte {tag, value} granules, one or
-// two per element of x). The reference's launcher signature has no handle to
+// Hand-off workspace of the solve kernels: a 4 KiB header (the
+// `trsv_state` of `kernel::trsv`) followed by 8-byte {tag, value} granules, one or
+// two per element of x. The reference's launcher signature has no handle to
 // keep it in, so the library owns one buffer per (device, stream) and grows it
 // on demand; growth is the only time a TRSV call allocates (and synchronises
-// that stream first, so a solve still reading the old buffer finishes).
+// that stream first, so a solve still reading the old buffer finishes). A new
+// buffer is zeroed once; `kernel::trsv` re-arms it itself (epoch tags).
 struct workspace_entry {
     void *ptr{nullptr};
     std::size_t bytes{0};
 };
 
-}  // namespace
+constexpr std::size_t workspace_header_bytes = 4096;
 
+std::mutex workspace_guard;
+std::map<std::pair<int, hipStream_t>, workspace_entry> workspace_cache;
 
-int accblas::trsv_get_workspace(hipStream_t stream, std::size_t bytes,
-                                accblas::dev::granule_word **out)
+/** Caller holds `workspace_guard`. */
+int ensure_workspace(hipStream_t stream, std::size_t granule_bytes,
+                     workspace_entry **out)
 {
-    static std::mutex guard;
-    static std::map<std::pair<int, hipStream_t>, workspace_entry> cache;
     int device = 0;
     int status = accblas::check_hip(hipGetDevice(&device), "hipGetDevice");
     if (status != ACCBLAS_OK) {
         return status;
     }
-    std::lock_guard<std::mutex> lock(guard);
-    auto &entry = cache[std::make_pair(device, stream)];
+    auto &entry = workspace_cache[std::make_pair(device, stream)];
+    const std::size_t bytes = granule_bytes + workspace_header_bytes;
     if (entry.bytes < bytes) {
         if (entry.ptr != nullptr) {
             status = accblas::check_hip(hipStreamSynchronize(stream),
@@ -96,9 +99,62 @@ int accblas::trsv_get_workspace(hipStream_t stream, std::size_t bytes,
             return status;
         }
         entry.bytes = rounded;
+        status = accblas::check_hip(
+            hipMemsetAsync(entry.ptr, 0, rounded, stream),
+            "hipMemsetAsync(trsv workspace)");
+        if (status != ACCBLAS_OK) {
+            return status;
+        }
+        // header = accblas::dev::trsv_state{0, 0, first epoch, 0}
+        static const accblas::dev::trsv_state initial{
+            0u, 0u, accblas::dev::trsv_first_epoch, 0u};
+        status = accblas::check_hip(
+            hipMemcpyAsync(entry.ptr, &initial, sizeof(initial),
+                           hipMemcpyHostToDevice, stream),
+            "hipMemcpyAsync(trsv state)");
+        if (status != ACCBLAS_OK) {
+            return status;
+        }
     }
-    *out = static_cast<accblas::dev::granule_word *>(entry.ptr);
+    *out = &entry;
     return ACCBLAS_OK;
+}
+
+accblas::dev::granule_word *granules_of(const workspace_entry &entry)
+{
+    return reinterpret_cast<accblas::dev::granule_word *>(
+        static_cast<char *>(entry.ptr) + workspace_header_bytes);
+}
+
+}  // namespace
+
+
+int accblas::trsv_get_workspace(hipStream_t stream, std::size_t bytes,
+                                accblas::dev::granule_word **out)
+{
+    std::lock_guard<std::mutex> lock(workspace_guard);
+    workspace_entry *entry = nullptr;
+    const int status = ensure_workspace(stream, bytes, &entry);
+    if (status == ACCBLAS_OK) {
+        *out = granules_of(*entry);
+    }
+    return status;
+}
+
+int accblas::trsv_get_session(hipStream_t stream, std::size_t bytes,
+                              accblas::dev::trsv_session *out)
+{
+    std::lock_guard<std::mutex> lock(workspace_guard);
+    workspace_entry *entry = nullptr;
+    const int status = ensure_workspace(stream, bytes, &entry);
+    if (status == ACCBLAS_OK) {
+        out->state = static_cast<accblas::dev::trsv_state *>(entry->ptr);
+        out->granules = granules_of(*entry);
+        out->capacity_words = static_cast<accblas::dev::index_type>(
+            (entry->bytes - workspace_header_bytes) /
+            sizeof(accblas::dev::granule_word));
+    }
+    return status;
 }
 
 

@@ -22,6 +22,10 @@ namespace accblas {
 int trsv_get_workspace(hipStream_t stream, std::size_t bytes,
                        dev::granule_word **out);
 
+/** The same workspace as `kernel::trsv` sees it (state header + granules). */
+int trsv_get_session(hipStream_t stream, std::size_t bytes,
+                     dev::trsv_session *out);
+
 /** Compute units of the current device (cached). */
 int trsv_num_cus();
 
@@ -36,41 +40,50 @@ template <typename ar_type, typename st_type, typename MtxView, typename XView>
 int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
                   const XView &x, uint32_t *helper, void *stream)
 {
-    dev::granule_word *granules = nullptr;
+    if (n <= 0) {
+        return ACCBLAS_OK;
+    }
     const std::size_t bytes =
         std::max(dev::trsv_workspace_bytes<st_type>(n),
                  dev::trsv_split_workspace_bytes<ar_type, st_type>(n));
-    const int ws_status = trsv_get_workspace(as_stream(stream), bytes, &granules);
-    if (ws_status != ACCBLAS_OK) {
-        return ws_status;
-    }
-    bool launched = false;
-    if (trsv_wide_enabled()) {
-        const int wide_status = check_hip(
-            dev::try_launch_trsv_wide<ar_type>(upper, unit_diag, mtx, x, helper,
-                                               granules, as_stream(stream),
-                                               &launched),
-            "trsv (128-row) launch");
-        if (wide_status != ACCBLAS_OK || launched) {
-            return wide_status;
+    // the opt-in kernels keep the two-launch protocol (trsv_init zeroes the
+    // granules before every solve)
+    if (trsv_wide_enabled() || trsv_split_enabled()) {
+        dev::granule_word *granules = nullptr;
+        const int ws_status =
+            trsv_get_workspace(as_stream(stream), bytes, &granules);
+        if (ws_status != ACCBLAS_OK) {
+            return ws_status;
+        }
+        bool launched = false;
+        if (trsv_wide_enabled()) {
+            const int wide_status = check_hip(
+                dev::try_launch_trsv_wide<ar_type>(upper, unit_diag, mtx, x,
+                                                   helper, granules,
+                                                   as_stream(stream), &launched),
+                "trsv (128-row) launch");
+            if (wide_status != ACCBLAS_OK || launched) {
+                return wide_status;
+            }
+        }
+        if (trsv_split_enabled()) {
+            const int split_status = check_hip(
+                dev::try_launch_trsv_split<ar_type>(
+                    upper, unit_diag, mtx, x, helper, granules, trsv_num_cus(),
+                    as_stream(stream), &launched),
+                "trsv (split) launch");
+            if (split_status != ACCBLAS_OK || launched) {
+                return split_status;
+            }
         }
     }
-    if (!trsv_split_enabled()) {
-        return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x,
-                                                   helper, granules,
-                                                   as_stream(stream)),
-                         "trsv launch");
-    }
-    const int split_status = check_hip(
-        dev::try_launch_trsv_split<ar_type>(upper, unit_diag, mtx, x, helper,
-                                            granules, trsv_num_cus(),
-                                            as_stream(stream), &launched),
-        "trsv (split) launch");
-    if (split_status != ACCBLAS_OK || launched) {
-        return split_status;
+    dev::trsv_session session{};
+    const int status = trsv_get_session(as_stream(stream), bytes, &session);
+    if (status != ACCBLAS_OK) {
+        return status;
     }
     return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x, helper,
-                                               granules, as_stream(stream)),
+                                               session, as_stream(stream)),
                      "trsv launch");
 }
 

@@ -18,20 +18,30 @@
 //     bottom-up block numbering with the ragged block at the top;
 //   * hand-off = the data IS the flag (guide G16, recipe R2): every solved
 //     element is published as one 8-byte {tag, value} granule with a single
-//     write-through (sc1) store into a zeroed workspace; consumers poll the
-//     granules they need with sc1 loads. No progress word, no drain, no fence
-//     on the critical path (the reference's __threadfence + volatile spin,
+//     write-through (sc1) store; consumers poll the granules they need with
+//     sc1 loads. No progress word, no drain, no fence on the critical path
+//     (the reference's __threadfence + volatile spin,
 //     `trsv_kernels.cuh:171-182,229-233`, would be 5 serialised memory round
 //     trips per hop here); per-XCD L2s are not coherent and L1 is never
 //     refreshed, so plain loads/stores are not an option;
+//   * ONE launch per solve: the tag is the solve's epoch, read from a small
+//     device-resident state that the last workgroup to finish re-arms for the
+//     next solve (`trsv_state`), so nothing is zeroed between solves, the
+//     reference's `trsv_init` launch disappears and a captured solve can be
+//     replayed from a hipGraph. A block's 64 granules are 512-byte aligned
+//     (4 cache lines; a 64-byte misalignment cost 4-8 % of the whole solve);
+//   * ONE workgroup per CU (`trsv_single_block_pad`): a second resident block
+//     would sweep on the SIMDs of the block that is on the chain;
 //   * per block: all waves stage the diagonal tile AND the last off-diagonal
-//     panel in LDS; wave 0 inverts the tile with each lane owning a column of
-//     the inverse in registers (2016 FMAs, no synchronisation, instead of a
-//     Gauss-Jordan sweep through shared memory with a sync per step);
+//     panel in LDS; the tile is inverted blockwise (two 32 x 32 forward
+//     substitutions by the two halves of wave 0, lanes owning columns in
+//     registers, then X10 = -X11 C X00 by all waves) instead of a Gauss-Jordan
+//     sweep through shared memory with a sync per step;
 //   * far panels (all but the last): 16-byte loads of the storage type,
 //     double-buffered in registers together with the x granules of the next
 //     panel, FMA in the arithmetic type, ONE cross-lane reduction at the end;
-//   * the last panel is folded with the inverse ahead of time,
+//   * the last panel is folded with the inverse ahead of time on the matrix
+//     cores (16 x 16 x 4 MFMA in the arithmetic type),
 //     M = inv(T_bb) A_{b,b-1}, so that x_b = inv(T_bb) rhs_far - M x_{b-1}:
 //     after x_{b-1} arrives ONE 64 x 64 mat-vec from LDS is left (lane = row,
 //     columns split over the waves, vector entries broadcast with v_readlane,
@@ -80,6 +90,36 @@ __device__ unsigned long long *trsv_diag_buffer;
 #endif
 
 
+/**
+ * Device-resident state of `kernel::trsv`'s hand-off workspace (its 64-byte
+ * header). The workspace is zeroed and this state initialised once, when the
+ * buffer is allocated; after that every solve is ONE launch that re-arms the
+ * workspace for its successor, with nothing kept on the host (so a captured
+ * launch can be replayed from a hipGraph):
+ *   - granules of a solve carry `epoch` in their tag word (0 = never written,
+ *     1 = written by a kernel of the `trsv_init` protocol, >= 2 = epochs);
+ *   - row blocks are numbered by tickets drawn from `next_ticket`;
+ *   - the last workgroup to finish (counted in `finished`) resets both
+ *     counters and moves `epoch` on; when the epoch would wrap it zeroes the
+ *     granules and starts again at 2.
+ */
+struct trsv_state {
+    unsigned int next_ticket;
+    unsigned int finished;
+    unsigned int epoch;
+    unsigned int reserved;
+};
+
+constexpr unsigned int trsv_first_epoch = 2;
+
+/** Kernel argument: where the state and the granules live. */
+struct trsv_session {
+    trsv_state *state;
+    granule_word *granules;
+    index_type capacity_words;  // granule words in the workspace
+};
+
+
 namespace kernel {
 
 
@@ -106,8 +146,6 @@ static __global__ __launch_bounds__(256) void trsv_init(
 
 namespace detail {
 
-
-constexpr granule_word granule_tag = granule_word{1} << 32;
 
 // Every spin is bounded: a wave that polled `trsv_spin_limit` times without
 // success (seconds; a healthy solve needs microseconds to milliseconds) writes
@@ -162,6 +200,40 @@ __device__ __forceinline__ T read_lane(T value, int src_lane)
     return out;
 }
 
+/** One 16 x 16 x 4 matrix-core step D = A B + C in T (v_mfma_f64_16x16x4_f64 /
+ *  v_mfma_f32_16x16x4_f32). Lane l supplies A[l & 15][l >> 4] and
+ *  B[l >> 4][l & 15] and holds D[row(l, reg)][l & 15], reg = 0..3. */
+template <typename T>
+struct mma_16x16x4;
+
+template <>
+struct mma_16x16x4<double> {
+    using acc_type = __attribute__((__vector_size__(4 * sizeof(double)))) double;
+    __device__ __forceinline__ static acc_type step(double a, double b,
+                                                    acc_type c)
+    {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    __device__ __forceinline__ static int row(int lane, int reg)
+    {
+        return (lane >> 4) + 4 * reg;
+    }
+};
+
+template <>
+struct mma_16x16x4<float> {
+    using acc_type = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+    __device__ __forceinline__ static acc_type step(float a, float b,
+                                                    acc_type c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __device__ __forceinline__ static int row(int lane, int reg)
+    {
+        return (lane >> 4) * 4 + reg;
+    }
+};
+
 /** sum_{w < Count} values[w * stride + lane], combined as a balanced tree
  *  (fixed order, so the result is reproducible). */
 template <int Count, typename T>
@@ -189,22 +261,27 @@ template <typename St>
 struct granule_io {
     static constexpr int words = trsv_granule_words<St>();
 
+    /** `tag` marks the granule as published in THIS solve: 1 for kernels
+     *  whose workspace is zeroed by `trsv_init` before every launch, the
+     *  solve's epoch (>= 2) for `kernel::trsv`, which never zeroes. */
     __device__ __forceinline__ static void publish(granule_word *granules,
-                                                   index_type element, St value)
+                                                   index_type element, St value,
+                                                   std::uint32_t tag = 1)
     {
+        const granule_word high = granule_word{tag} << 32;
         if (words == 1) {
             unsigned int bits = 0;
             __builtin_memcpy(&bits, &value, sizeof(St));
-            __hip_atomic_store(granules + element, granule_tag | bits,
+            __hip_atomic_store(granules + element, high | bits,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             granule_word bits = 0;
             __builtin_memcpy(&bits, &value, sizeof(St));
             __hip_atomic_store(granules + 2 * element,
-                               granule_tag | (bits & 0xffffffffull),
+                               high | (bits & 0xffffffffull),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(granules + 2 * element + 1,
-                               granule_tag | (bits >> 32), __ATOMIC_RELAXED,
+                               high | (bits >> 32), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -222,12 +299,12 @@ struct granule_io {
     }
 
     __device__ __forceinline__ static bool ready(
-        const granule_word (&raw)[words])
+        const granule_word (&raw)[words], std::uint32_t tag = 1)
     {
         bool ok = true;
 #pragma unroll
         for (int w = 0; w < words; ++w) {
-            ok = ok && (raw[w] >> 32) == 1;
+            ok = ok && (raw[w] >> 32) == tag;
         }
         return ok;
     }
@@ -271,7 +348,7 @@ struct granule_io {
 template <int Waves, bool Upper, bool UnitDiag, int Vec, typename ArType,
           typename MtxView, typename XView>
 __global__ __launch_bounds__(Waves *wave_size) void trsv(
-    MtxView mtx, XView x, std::uint32_t *helper, granule_word *granules)
+    MtxView mtx, XView x, std::uint32_t *helper, trsv_session session)
 {
     using ar_type = decltype(mtx(0, 0) * x(0, 0));
     static_assert(std::is_same<ArType, ar_type>::value,
@@ -302,16 +379,34 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     const int wave = wave_id();
     const index_type n = mtx.length(0);
 
+    granule_word *const granules = session.granules;
+    __shared__ std::uint32_t shared_epoch;
     if (threadIdx.x == 0) {
-        shared_block = static_cast<std::int32_t>(
-            __hip_atomic_fetch_add(helper + 1, 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT));
+        // the previous solve on this workspace finished before this kernel
+        // started (stream order), so the epoch is stable for the whole solve
+        const unsigned int ticket = __hip_atomic_fetch_add(
+            &session.state->next_ticket, 1u, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+        shared_epoch = __hip_atomic_load(&session.state->epoch,
+                                         __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+        shared_block = static_cast<std::int32_t>(ticket);
+        if (ticket == 0) {
+            // `trsv_init` (cuda/trsv_kernels.cuh:38-42) folded into the first
+            // block: helper[0] stays ~0 unless a bounded spin expires (nobody
+            // looks at it before 1024 unsuccessful polls), helper[1] mirrors
+            // the reference's block counter after the solve
+            __hip_atomic_store(helper, ~std::uint32_t{0}, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            helper[1] = gridDim.x;
+        }
     }
     __syncthreads();
     const index_type block = shared_block;
+    const std::uint32_t epoch = shared_epoch;
     const index_type base = block * B;
     if (base >= n) {
-        return;
+        return;  // cannot happen: the grid has exactly ceil(n / B) blocks
     }
     if (wave == 0) {
         ACCBLAS_TRSV_STAMP(block, 0);  // ticket drawn
@@ -335,53 +430,115 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     }
 
     // ---- diagonal tile and last panel -> LDS (a wave reads one row) -------
-    for (int r = wave; r < B; r += Waves) {
-        const index_type gr = base + r;
-        const index_type gc = base + lane;
-        ar_type value{};
-        if (lane == r) {
-            value = (UnitDiag || gr >= n) ? ar_type{1}
-                                          : ar_type(mtx(phys(gr), phys(gc)));
-        } else if (lane < r && gr < n) {
-            value = mtx(phys(gr), phys(gc));
-        }
-        tile[r * ld + lane] = value;
-        if (block > 0) {
-            ar_type off{};
-            if (gr < n) {
-                off = mtx(phys(gr), phys(base - B + lane));
+    // every load of the wave's rows is issued before the first LDS store, so
+    // the staging costs one memory latency, not one per row
+    {
+        constexpr int RS = B / Waves;  // rows a wave stages
+        ar_type diag_value[RS];
+        ar_type panel_value[RS];
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            const int r = wave + i * Waves;
+            const index_type gr = base + r;
+            const index_type gc = base + lane;
+            diag_value[i] = ar_type{};
+            if (lane == r) {
+                diag_value[i] = (UnitDiag || gr >= n)
+                                    ? ar_type{1}
+                                    : ar_type(mtx(phys(gr), phys(gc)));
+            } else if (lane < r && gr < n) {
+                diag_value[i] = mtx(phys(gr), phys(gc));
             }
-            panel[lane * ld + r] = off;
+            panel_value[i] = ar_type{};
+            if (block > 0 && gr < n) {
+                panel_value[i] = mtx(phys(gr), phys(base - B + lane));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            const int r = wave + i * Waves;
+            tile[r * ld + lane] = diag_value[i];
+            if (block > 0) {
+                panel[lane * ld + r] = panel_value[i];
+            }
         }
     }
     __syncthreads();
 
-    // ---- invert the tile: lane j computes column j of the inverse --------
-    // X = T^{-1}: X[i][j] = (delta_ij - sum_{k<i} T[i][k] X[k][j]) / T[i][i]
     if (wave == 0) {
-        ar_type column[B];
+        ACCBLAS_TRSV_STAMP(block, 10);  // tile and panel staged
+    }
+
+    // ---- invert the tile blockwise ----------------------------------------
+    // T = [T00 0; C T11] (32 x 32 blocks): inv = [X00 0; -X11 C X00, X11].
+    // Step 1, wave 0: lanes 0..31 own the columns of X00 = inv(T00), lanes
+    // 32..63 those of X11 = inv(T11), in registers, by forward substitution:
+    // X[i][j] = (delta_ij - sum_{k<i} T[i][k] X[k][j]) / T[i][i]. Both halves
+    // run the same instruction stream, so this costs 32 dependent rows, not 64.
+    constexpr int H = B / 2;
+    const int half = lane / H;
+    const int sub = lane % H;
+    if (wave == 0) {
+        const int off = half * H;
+        ar_type column[H];
 #pragma unroll
-        for (int i = 0; i < B; ++i) {
+        for (int i = 0; i < H; ++i) {
             // a dependent fp64 FMA chain costs ~40 cycles per link on gfx950:
             // four interleaved partial sums cut the row's latency by 4
             ar_type sums[4] = {};
 #pragma unroll
             for (int k = 0; k < i; ++k) {
-                sums[k & 3] += tile[i * ld + k] * column[k];  // LDS broadcast
+                sums[k & 3] += tile[(off + i) * ld + off + k] * column[k];
             }
-            ar_type value = ((lane == i) ? ar_type{1} : ar_type{0}) -
+            ar_type value = ((sub == i) ? ar_type{1} : ar_type{0}) -
                             ((sums[0] + sums[1]) + (sums[2] + sums[3]));
             if (!UnitDiag) {
-                value = value / tile[i * ld + i];
+                value = value / tile[(off + i) * ld + off + i];
             }
             column[i] = value;
         }
-        // all reads of T are done (same wave, program order): overwrite with
-        // the inverse, column-major
+        // all reads of T00 / T11 are done (same wave, program order): overwrite
+        // them with their inverses, column-major
 #pragma unroll
-        for (int i = 0; i < B; ++i) {
-            tile[lane * ld + i] = column[i];
+        for (int i = 0; i < H; ++i) {
+            tile[(off + sub) * ld + off + i] = column[i];
         }
+    }
+    __syncthreads();
+    // Step 2, all waves: X10 = -X11 (C X00), one column per half wave (lane =
+    // row). p = C X00[:, c] stays lane-local, is handed to the other lanes of
+    // the half through this wave's slice of partial_a, then X11 p. The result
+    // goes to tile[c * ld + H + r], the (zero) upper-right block of T in
+    // row-major terms, which nobody reads in this phase.
+    {
+        constexpr int cols_per_wave = H / Waves;
+        static_assert(cols_per_wave % 2 == 0, "two columns per pass");
+        ar_type *hand = partial_a + wave * B + half * H;
+        for (int pass = 0; pass < cols_per_wave / 2; ++pass) {
+            const int c = wave * cols_per_wave + pass * 2 + half;
+            ar_type p[4] = {};
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                // X00 is lower triangular: entries above the diagonal are the
+                // zeros T held there
+                p[k & 3] += tile[(H + sub) * ld + k] * tile[c * ld + k];
+            }
+            hand[sub] = (p[0] + p[1]) + (p[2] + p[3]);
+            ar_type q[4] = {};
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                q[k & 3] += tile[(H + k) * ld + H + sub] * hand[k];
+            }
+            tile[c * ld + H + sub] = -((q[0] + q[1]) + (q[2] + q[3]));
+        }
+    }
+    __syncthreads();
+    // C (row-major, rows >= H, columns < H) is dead now; in column-major terms
+    // that region is the upper-right block of the inverse: zero
+    for (int e = threadIdx.x; e < H * H; e += Waves * wave_size) {
+        tile[(H + e / H) * ld + e % H] = ar_type{};
+    }
+    if (wave == 0) {
         ACCBLAS_TRSV_STAMP(block, 1);  // inverse ready
     }
     __syncthreads();
@@ -389,40 +546,69 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     // ---- fold the inverse into the last panel: M = inv(T_bb) * A_{b,b-1} ---
     // x_b = inv(T) (rhs_far - A_{b,b-1} x_{b-1}) = inv(T) rhs_far - M x_{b-1}:
     // with M prepared here, off the critical path, only ONE mat-vec is left
-    // between the arrival of x_{b-1} and the publication of x_b. Each wave
-    // computes CW columns of M (lane = row) and overwrites the same columns of
-    // `panel`; the lane's row of the inverse is held in registers.
+    // between the arrival of x_{b-1} and the publication of x_b. This is the
+    // one dense 64 x 64 x 64 product of the kernel, so it runs on the matrix
+    // cores: 16 output tiles of 16 x 16 spread over the waves, 16 x 16 x 4
+    // MFMA steps in the arithmetic type (exact fp64 / fp32 FMAs), operands
+    // fetched from LDS one element per lane. inv(T) is lower triangular, so a
+    // row tile stops at its own diagonal tile.
     constexpr int CW = B / Waves;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     if (block > 0) {
-        ar_type inv_row[B];
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-            inv_row[k] = tile[k * ld + lane];
-        }
-        constexpr int CG = 4;  // columns per pass: independent FMA chains
-        static_assert(CW % CG == 0, "CW must be a multiple of 4");
-        for (int c0 = 0; c0 < CW; c0 += CG) {
-            const int col = wave_u * CW + c0;
-            ar_type m[CG];
-#pragma unroll
-            for (int q = 0; q < CG; ++q) {
-                m[q] = ar_type{};
+        using mma = detail::mma_16x16x4<ar_type>;
+        constexpr int tiles_per_wave = 16 / Waves;
+        static_assert(tiles_per_wave >= 1 && 16 % Waves == 0,
+                      "16 output tiles must split evenly over the waves");
+        const int frag_ij = lane & 15;  // row of A / column of B
+        const int frag_k = lane >> 4;
+        // tile (ti, tj) of M costs ti + 1 passes over 16 columns of inv(T):
+        // with 8 waves a wave takes row tiles {0, 3} or {1, 2} of one column
+        // tile, five passes each
+        const auto tile_of = [&](int t, int &ti, int &tj) {
+            if (Waves == 8) {
+                tj = wave_u % 4;
+                ti = (t == 0) ? wave_u / 4 : 3 - wave_u / 4;
+            } else {
+                ti = (wave_u * tiles_per_wave + t) / 4;
+                tj = (wave_u * tiles_per_wave + t) % 4;
             }
+        };
+        typename mma::acc_type m_tile[tiles_per_wave];
 #pragma unroll
-            for (int k = 0; k < B; ++k) {
+        for (int t = 0; t < tiles_per_wave; ++t) {
+            int ti, tj;
+            tile_of(t, ti, tj);
+            typename mma::acc_type acc{};
+            for (int pass = 0; pass <= ti; ++pass) {
+                // all eight operand loads of a pass are issued before the
+                // first of its four dependent MFMAs
+                ar_type a[4];
+                ar_type b[4];
 #pragma unroll
-                for (int q = 0; q < CG; ++q) {
-                    m[q] += inv_row[k] * panel[(col + q) * ld + k];
+                for (int q = 0; q < 4; ++q) {
+                    const int k = pass * 16 + q * 4 + frag_k;
+                    a[q] = tile[k * ld + ti * 16 + frag_ij];
+                    b[q] = panel[(tj * 16 + frag_ij) * ld + k];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc = mma::step(a[q], b[q], acc);
                 }
             }
-            // every lane of this wave has read the CG columns (program order
-            // within a wave; other waves never touch these columns)
+            m_tile[t] = acc;
+        }
+        __syncthreads();  // every wave is done reading A_{b,b-1}
 #pragma unroll
-            for (int q = 0; q < CG; ++q) {
-                panel[(col + q) * ld + lane] = m[q];
+        for (int t = 0; t < tiles_per_wave; ++t) {
+            int ti, tj;
+            tile_of(t, ti, tj);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                panel[(tj * 16 + frag_ij) * ld + ti * 16 +
+                      mma::row(lane, reg)] = m_tile[t][reg];
             }
         }
+        // readers of M wait behind the barrier that ends the far sweep
     }
     if (wave == 0) {
         ACCBLAS_TRSV_STAMP(block, 6);  // M ready
@@ -479,7 +665,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
             bool ok = true;
 #pragma unroll
             for (int e = 0; e < Vec; ++e) {
-                ok = ok && io::ready(s.xraw[e]);
+                ok = ok && io::ready(s.xraw[e], epoch);
             }
             if (__all(ok) || detail::spin_expired(spins, helper)) {
                 break;
@@ -578,7 +764,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
             granule_word raw[io::words];
             const index_type prev = base - B + lane;  // always < n
             io::load(granules, prev, raw);
-            while (!__all(io::ready(raw)) &&
+            while (!__all(io::ready(raw, epoch)) &&
                    !detail::spin_expired(spins, helper)) {
                 io::load(granules, prev, raw);
             }
@@ -611,10 +797,42 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
         }
         const st_type solution = static_cast<st_type>(sum);
         if (own_valid) {
-            io::publish(granules, own_row, solution);  // hand-off first
+            io::publish(granules, own_row, solution, epoch);  // hand-off
             *own_addr = solution;                       // the user's vector
         }
         ACCBLAS_TRSV_STAMP(block, 5);  // published
+    }
+    // ---- re-arm the workspace for the next solve (off the critical path) ---
+    // A block is done with the workspace once its solution is published; the
+    // last one to say so is alone and resets the counters for its successor.
+    __shared__ bool is_last;
+    if (threadIdx.x == 0) {
+        const unsigned int done = __hip_atomic_fetch_add(
+            &session.state->finished, 1u, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+        is_last = done == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last) {
+        std::uint32_t next_epoch = epoch + 1;
+        if (next_epoch == 0) {
+            // 2^32 solves on this workspace: stale tags could repeat
+            for (index_type i = threadIdx.x; i < session.capacity_words;
+                 i += Waves * wave_size) {
+                __hip_atomic_store(granules + i, granule_word{0},
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            next_epoch = trsv_first_epoch;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&session.state->next_ticket, 0u,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&session.state->finished, 0u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&session.state->epoch, next_epoch,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -631,10 +849,38 @@ constexpr std::size_t trsv_workspace_bytes(index_type n)
 }
 
 
+/**
+ * Dynamic LDS requested on top of the kernel's static arrays so that exactly
+ * ONE workgroup is resident per CU (160 KiB of LDS). A second resident block
+ * puts its far sweep on the same SIMDs, LDS and memory pipes as the block
+ * that is on the critical chain: measured with two per CU, n = 65536 took
+ * 2.65 ms instead of 2.32 ms and fp64 storage at n = 24000 1.82 ms instead of
+ * 0.91 ms (profiles/r01_trsv_occupancy.txt).
+ */
+template <typename ArType, int Waves>
+constexpr unsigned trsv_single_block_pad()
+{
+    constexpr std::size_t B = trsv_tile;
+    constexpr std::size_t static_bytes =
+        sizeof(ArType) * (2 * B * (B + 1) + 2 * B + 2 * Waves * B) + 16;
+    constexpr std::size_t needed = 160 * 1024 / 2 + 2048;
+    return static_bytes >= needed
+               ? 0u
+               : static_cast<unsigned>(needed - static_bytes);
+}
+
+
+/** Workgroups (= tickets) a solve of n unknowns launches. */
+inline unsigned trsv_num_blocks(index_type n)
+{
+    return static_cast<unsigned>(ceildiv(n, index_type{trsv_tile}));
+}
+
+
 template <typename ArType, typename MtxView, typename XView>
 hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
                        const XView &x, std::uint32_t *helper,
-                       granule_word *granules, hipStream_t stream)
+                       const trsv_session &session, hipStream_t stream)
 {
     using mtx_traits = view_traits<MtxView>;
     using st_type =
@@ -645,23 +891,19 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     }
     constexpr int waves = trsv_waves;
     constexpr int vec16 = 16 / sizeof(st_type);
-    const dim3 grid(static_cast<unsigned>(ceildiv(n, trsv_tile)), 1, 1);
+    const dim3 grid(trsv_num_blocks(n), 1, 1);
     const dim3 block(waves * wave_size, 1, 1);
-    const index_type num_words = n * trsv_granule_words<st_type>();
-    const unsigned init_blocks =
-        static_cast<unsigned>(std::min<index_type>(ceildiv(num_words, 256), 512));
-    kernel::trsv_init<<<init_blocks, 256, 0, stream>>>(helper, granules,
-                                                       num_words);
+    constexpr unsigned pad = trsv_single_block_pad<ArType, waves>();
     const bool vec_ok = is_aligned(mtx_traits::data(mtx), 16) &&
                         mtx_traits::stride(mtx) % vec16 == 0 &&
                         (!upper || n % vec16 == 0);
 #define ACCBLAS_TRSV_LAUNCH(_upper, _unit)                                     \
     if (vec_ok) {                                                              \
         kernel::trsv<waves, _upper, _unit, vec16, ArType>                      \
-            <<<grid, block, 0, stream>>>(mtx, x, helper, granules);            \
+            <<<grid, block, pad, stream>>>(mtx, x, helper, session);           \
     } else {                                                                   \
         kernel::trsv<waves, _upper, _unit, 1, ArType>                          \
-            <<<grid, block, 0, stream>>>(mtx, x, helper, granules);            \
+            <<<grid, block, pad, stream>>>(mtx, x, helper, session);           \
     }
     if (upper) {
         if (unit_diag) {

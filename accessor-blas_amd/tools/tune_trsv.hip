@@ -59,6 +59,12 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&x0, n * sizeof(st_type)));
     CHECK(hipMalloc(&helper, 16));
     CHECK(hipMalloc(&granules, n * 16));
+    CHECK(hipMemset(granules, 0, n * 16));
+    trsv_state *state;
+    CHECK(hipMalloc(&state, 64));
+    const trsv_state initial{0u, 0u, trsv_first_epoch, 0u};
+    CHECK(hipMemcpy(state, &initial, sizeof(initial), hipMemcpyHostToDevice));
+    const trsv_session session{state, granules, index_type(n) * 2};
     fill<<<4096, 256>>>(A, size_t(n) * n, 1, 1.0f / std::sqrt(float(n)));
     fill<<<64, 256>>>(x0, n, 2, 1.0f);
     using sz = std::array<gko::acc::size_type, 2>;
@@ -69,8 +75,7 @@ int main(int argc, char **argv)
 
     auto make = [&](const char *name, auto kernel, int threads, size_t dyn_lds) {
         return entry{name, [=]() {
-                         kernel::trsv_init<<<512, 256>>>(helper, granules, n);
-                         kernel<<<blocks, threads, dyn_lds>>>(m, xv, helper, granules);
+                         kernel<<<blocks, threads, dyn_lds>>>(m, xv, helper, session);
                      }};
     };
     std::vector<entry> entries = {
@@ -124,7 +129,8 @@ int main(int argc, char **argv)
         std::printf("block: ticket  inv_done  w0_far  all_far  seen  published | hop  seen-prev_pub  pub-seen  allfar-prevprev_pub\n");
         for (unsigned b : {0u, 1u, 2u, 3u, 10u, 11u, 12u, 100u, 101u, 102u, 200u, 201u, 300u, 301u, 500u, 501u, 800u, 801u, 1000u, 1001u}) {
             if (b >= blocks) continue;
-            std::printf("%5u: %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f | %6.2f %6.2f %6.2f %6.2f | seen->bar1 %5.2f matvec %5.2f bar2 %5.2f sum+pub %5.2f\n", b, us(b, 0), us(b, 1), us(b, 2),
+            std::printf("%5u: staged %6.2f M_ready %6.2f |", b, us(b, 10), us(b, 6));
+            std::printf(" %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f | %6.2f %6.2f %6.2f %6.2f | seen->bar1 %5.2f matvec %5.2f bar2 %5.2f sum+pub %5.2f\n", us(b, 0), us(b, 1), us(b, 2),
                         us(b, 3), us(b, 4), us(b, 5), b ? us(b, 5) - us(b - 1, 5) : 0.0,
                         b ? us(b, 4) - us(b - 1, 5) : 0.0, us(b, 5) - us(b, 4),
                         b > 1 ? us(b, 3) - us(b - 2, 5) : 0.0, us(b, 7) - us(b, 4), us(b, 8) - us(b, 7),

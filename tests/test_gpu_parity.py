@@ -400,6 +400,47 @@ def test_trsv_workspace_grows_and_helper_reports_no_timeout(gpu):
         assert oracle.rel_error(want, dx.cpu().numpy()) <= 1e-11
 
 
+def test_trsv_workspace_rearms_itself_between_solves(gpu):
+    """One launch per solve: granules of earlier (larger, smaller, other storage
+    type) solves and of the opt-in kernels' `trsv_init` protocol stay in the
+    workspace and must never be taken for this solve's; back-to-back launches
+    without a host synchronisation in between must each see a re-armed state."""
+    torch, accblas = gpu
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    plan = [(5000, F32, None), (1300, F32, None), (1300, F64, None), (5000, F16, None),
+            (4224, F32, "trsv_wide"), (4224, F32, None), (4224, F32, "trsv_split"),
+            (4224, F32, None), (70, F32, None), (5000, F32, None)]
+    cases = {}
+    for n, st, _ in plan:
+        if (n, st) not in cases:
+            A = oracle.convert(triangular_system(n, n, False, 7 * n), st)
+            b = make_inputs(60 + n, n, st)
+            cases[(n, st)] = (to_dev(torch, A), b,
+                              oracle.exact_trsv(F64, False, True, n, A, n, b, 1))
+    outputs = []
+    for n, st, option in plan:  # no synchronisation inside this loop
+        dA, b, _ = cases[(n, st)]
+        dx = to_dev(torch, b)
+        if option:
+            accblas.set_option(option, 1)
+        try:
+            accblas.acc_trsv(F64, st, accblas.LOWER, accblas.UNIT, n, dA, n, dx, 1, helper)
+            accblas.acc_trsv(F64, st, accblas.LOWER, accblas.UNIT, n, dA, n, dx, 1, helper)
+        finally:
+            if option:
+                accblas.set_option(option, 0)
+        outputs.append(dx)
+    torch.cuda.synchronize()
+    assert int(helper[0].item()) & 0xffffffff == 0xffffffff
+    for (n, st, option), dx in zip(plan, outputs):
+        dA, b, once = cases[(n, st)]
+        # x was solved twice in place: T^-1 T^-1 b
+        twice = oracle.exact_trsv(F64, False, True, n, dA.cpu().numpy(), n,
+                                  once.astype(b.dtype), 1)
+        err = oracle.rel_error(twice.astype(np.float64), dx.cpu().numpy().astype(np.float64))
+        assert err <= 100 * out_tolerance(F64, st), (n, st, option, err)
+
+
 @pytest.mark.parametrize("src,dst", [(F64, F32), (F64, F16), (F32, F16), (F16, F64),
                                      (F32, F64), (F16, F32)])
 def test_device_convert_is_the_reference_static_cast(gpu, src, dst):
