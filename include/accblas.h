@@ -164,7 +164,14 @@ int accblas_acc_dot(accblas_handle *handle, accblas_dtype ar, accblas_dtype st,
 /* ---- TRSV: x <- T^{-1} x in place ----------------------------------------
  * T = upper/lower triangle of the row-major n x n matrix A (row stride lda),
  * unit or non-unit diagonal. `helper` = 2 device uint32 words owned by the
- * caller (cuda/trsv_benchmark.cu:98); NULL is not accepted. */
+ * caller (cuda/trsv_benchmark.cu:98); NULL is not accepted. A solve is ONE
+ * kernel launch (the reference's `trsv_init` launch, trsv_kernels.cuh:38-42, is
+ * folded into it; nothing is kept on the host, so a captured call can be
+ * replayed from a hipGraph). After the solve helper[0] is 0xffffffff, or
+ * 0xdeadbeef if an internal wait gave up (the result is then invalid; it
+ * cannot happen on a healthy device), and helper[1] is the number of 64-row
+ * blocks. The hand-off workspace between row blocks is owned by the library,
+ * one per (device, stream); calls on one stream serialise as usual. */
 
 /* `trsv<ValueType>` (cuda/trsv_kernels.cuh:455-488 -> kernels :38-42,
  * :69-235, :263-432). */

@@ -386,6 +386,44 @@ def test_launches_on_a_side_stream_and_hipgraph_replay(gpu):
     handle.close()
 
 
+def test_trsv_concurrent_streams_and_host_threads(gpu):
+    """Solves on different streams use different workspaces and may overlap on
+    the device; two host threads may drive them at the same time."""
+    import threading
+    torch, accblas = gpu
+    n = 3000
+    A = to_dev(torch, oracle.convert(triangular_system(n, n, True, 91), F32))
+    b = make_inputs(92, n, F32)
+    want = oracle.exact_trsv(F64, True, False, n, A.cpu().numpy(), n, b, 1)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    helpers = [torch.zeros(2, dtype=torch.int32, device="cuda") for _ in streams]
+    solutions = [[to_dev(torch, b) for _ in range(6)] for _ in streams]
+    torch.cuda.synchronize()
+    failures = []
+
+    def drive(which):
+        try:
+            for dx in solutions[which]:
+                accblas.acc_trsv(F64, F32, accblas.UPPER, accblas.NON_UNIT, n, A, n, dx, 1,
+                                 helpers[which], streams[which])
+        except Exception as exc:  # surfaced in the main thread
+            failures.append(exc)
+
+    threads = [threading.Thread(target=drive, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not failures, failures
+    for which in range(2):
+        assert int(helpers[which][0].item()) & 0xffffffff == 0xffffffff
+        for dx in solutions[which]:
+            err = oracle.rel_error(want.astype(np.float64),
+                                   dx.cpu().numpy().astype(np.float64))
+            assert err <= 100 * out_tolerance(F64, F32), err
+
+
 def test_trsv_workspace_grows_and_helper_reports_no_timeout(gpu):
     torch, accblas = gpu
     helper = torch.zeros(2, dtype=torch.int32, device="cuda")
