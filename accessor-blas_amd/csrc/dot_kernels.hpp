@@ -122,7 +122,7 @@ __global__ __launch_bounds__(Config::waves *wave_size) void dot(
         acc[u] = ar_type{};
     }
 
-    if (Vec > 1) {
+    if constexpr (Vec > 1) {
         const st_type *x_ptr = x_traits::data(x);
         const st_type *y_ptr = y_traits::data(y);
         const index_type all_chunks = n / Vec;
@@ -293,7 +293,14 @@ hipError_t launch_dot_with(const dot_workspace &ws, bool atomic,
     }
     const dim3 grid(blocks, 1, 1);
     const dim3 block(waves * wave_size, 1, 1);
-    const bool vec_ok = (x_traits::stride(x) == 1 || n <= 1) &&
+    // the 16-byte path reads both operands as plain storage of ONE type;
+    // other accessor kinds and mixed storage types go through operator()
+    constexpr bool can_vec =
+        x_traits::is_pointer_view && y_traits::is_pointer_view &&
+        std::is_same<st_type, std::remove_cv_t<
+                                  typename y_traits::storage_type>>::value;
+    constexpr int vec = can_vec ? vec16 : 1;
+    const bool vec_ok = can_vec && (x_traits::stride(x) == 1 || n <= 1) &&
                         (y_traits::stride(y) == 1 || n <= 1) &&
                         is_aligned(x_traits::data(x), 16) &&
                         is_aligned(y_traits::data(y), 16);
@@ -306,7 +313,7 @@ hipError_t launch_dot_with(const dot_workspace &ws, bool atomic,
                                : static_cast<ArType *>(ws.scalar);
         kernel::init_res<<<1, 64, 0, stream>>>(accum);
         if (vec_ok) {
-            kernel::dot<Config, vec16, true>
+            kernel::dot<Config, vec, true>
                 <<<grid, block, 0, stream>>>(x, y, accum, ws.ticket, res);
         } else {
             kernel::dot<Config, 1, true>
@@ -317,7 +324,7 @@ hipError_t launch_dot_with(const dot_workspace &ws, bool atomic,
         }
     } else {
         if (vec_ok) {
-            kernel::dot<Config, vec16, false>
+            kernel::dot<Config, vec, false>
                 <<<grid, block, 0, stream>>>(x, y, partials, ws.ticket, res);
         } else {
             kernel::dot<Config, 1, false>

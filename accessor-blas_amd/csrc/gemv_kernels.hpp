@@ -315,27 +315,38 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
     const dim3 block(Config::waves * wave_size, 1, 1);
     const dim3 grid(
         static_cast<unsigned>(ceildiv(rows, Config::rows_per_block)), 1, 1);
-    if (lda % vec16 == 0 && is_aligned(a_ptr, 16)) {
-        if (unit_x && is_aligned(x_ptr, 16)) {
-            kernel::gemv_vec<Config, vec16, true>
-                <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
-        } else {
-            kernel::gemv_vec<Config, vec16, false>
-                <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
-        }
-    } else if (vec8 > 1 && lda % vec8 == 0 && is_aligned(a_ptr, 8)) {
-        if (unit_x && is_aligned(x_ptr, 8)) {
-            kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), true>
-                <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
-        } else {
-            kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), false>
-                <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
-        }
-    } else {
+    // accessor kinds whose elements are not plain storage (scaled, ...) only
+    // exist through operator()
+    constexpr bool pointer_views =
+        mtx_traits::is_pointer_view && x_traits::is_pointer_view;
+    const auto launch_generic = [&]() {
         constexpr int waves = 4;
         kernel::gemv_generic<waves>
             <<<dim3(static_cast<unsigned>(ceildiv(rows, waves))),
                dim3(waves * wave_size), 0, stream>>>(alpha, mtx, x, beta, res);
+    };
+    if constexpr (!pointer_views) {
+        launch_generic();
+    } else {
+        if (lda % vec16 == 0 && is_aligned(a_ptr, 16)) {
+            if (unit_x && is_aligned(x_ptr, 16)) {
+                kernel::gemv_vec<Config, vec16, true>
+                    <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+            } else {
+                kernel::gemv_vec<Config, vec16, false>
+                    <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+            }
+        } else if (vec8 > 1 && lda % vec8 == 0 && is_aligned(a_ptr, 8)) {
+            if (unit_x && is_aligned(x_ptr, 8)) {
+                kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), true>
+                    <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+            } else {
+                kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), false>
+                    <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+            }
+        } else {
+            launch_generic();
+        }
     }
     return hipGetLastError();
 }

@@ -885,6 +885,10 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     using mtx_traits = view_traits<MtxView>;
     using st_type =
         std::remove_cv_t<typename view_traits<XView>::storage_type>;
+    static_assert(mtx_traits::is_pointer_view &&
+                      view_traits<XView>::is_pointer_view,
+                  "the solve streams the triangle with loads of the storage "
+                  "type: reduced_row_major / row_major / plain views only");
     const index_type n = mtx.length(0);
     if (n <= 0) {
         return hipSuccess;

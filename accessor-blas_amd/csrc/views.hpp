@@ -18,6 +18,7 @@
 
 #include <accessor/range.hpp>
 #include <accessor/reduced_row_major.hpp>
+#include <accessor/row_major.hpp>
 
 
 namespace accblas {
@@ -52,11 +53,39 @@ struct plain_view {
 };
 
 
+/**
+ * What the vector fast paths need from a view. `is_pointer_view` says whether
+ * element (i, j) IS storage[i * stride + j] converted with a static_cast, i.e.
+ * whether 16-byte loads of the storage type may replace `operator()`. It holds
+ * for plain pointers, `reduced_row_major` and `row_major`; any other accessor
+ * kind (e.g. `scaled_reduced_row_major`, whose values are storage * scalar)
+ * gets the fallback below and runs through the kernels' `operator()` paths
+ * ("all others work accordingly", `/root/reference/README.md:19`).
+ */
 template <typename View>
 struct view_traits;
 
+template <typename Accessor>
+struct view_traits<gko::acc::range<Accessor>> {
+    static constexpr bool is_pointer_view = false;
+    using storage_type = typename Accessor::storage_type;
+    using arithmetic_type = typename Accessor::arithmetic_type;
+
+    __host__ __device__ static __forceinline__ storage_type *data(
+        const gko::acc::range<Accessor> &)
+    {
+        return nullptr;
+    }
+    __host__ __device__ static __forceinline__ index_type stride(
+        const gko::acc::range<Accessor> &)
+    {
+        return 0;
+    }
+};
+
 template <typename ValueType>
 struct view_traits<plain_view<ValueType>> {
+    static constexpr bool is_pointer_view = true;
     using storage_type = ValueType;
     using arithmetic_type = std::remove_cv_t<ValueType>;
 
@@ -75,12 +104,33 @@ struct view_traits<plain_view<ValueType>> {
 template <typename ArType, typename StType>
 struct view_traits<
     gko::acc::range<gko::acc::reduced_row_major<2, ArType, StType>>> {
+    static constexpr bool is_pointer_view = true;
     using range_type =
         gko::acc::range<gko::acc::reduced_row_major<2, ArType, StType>>;
     using storage_type = StType;
     using arithmetic_type = std::remove_cv_t<ArType>;
 
     __host__ __device__ static __forceinline__ StType *data(
+        const range_type &r)
+    {
+        return r->get_stored_data();
+    }
+    __host__ __device__ static __forceinline__ index_type stride(
+        const range_type &r)
+    {
+        return r->stride(0);
+    }
+};
+
+
+template <typename ValueType>
+struct view_traits<gko::acc::range<gko::acc::row_major<ValueType, 2>>> {
+    static constexpr bool is_pointer_view = true;
+    using range_type = gko::acc::range<gko::acc::row_major<ValueType, 2>>;
+    using storage_type = ValueType;
+    using arithmetic_type = std::remove_cv_t<ValueType>;
+
+    __host__ __device__ static __forceinline__ ValueType *data(
         const range_type &r)
     {
         return r->get_stored_data();
