@@ -38,8 +38,8 @@
 //     registers, then X10 = -X11 C X00 by all waves) instead of a Gauss-Jordan
 //     sweep through shared memory with a sync per step;
 //   * far panels (all but the last): 16-byte loads of the storage type,
-//     double-buffered in registers together with the x granules of the next
-//     panel, FMA in the arithmetic type, ONE cross-lane reduction at the end;
+//     four panels deep in registers together with the x granules of those
+//     panels, FMA in the arithmetic type, ONE cross-lane reduction at the end;
 //   * the last panel is folded with the inverse ahead of time on the matrix
 //     cores (16 x 16 x 4 MFMA in the arithmetic type),
 //     M = inv(T_bb) A_{b,b-1}, so that x_b = inv(T_bb) rhs_far - M x_{b-1}:
@@ -60,7 +60,11 @@ namespace dev {
 
 constexpr int trsv_tile = wave_size;  // 64
 constexpr int trsv_waves = 8;         // waves per workgroup
-constexpr int trsv_prefetch_depth = 2;  // far panels in flight per wave
+#ifndef ACCBLAS_TRSV_PREFETCH_DEPTH
+#define ACCBLAS_TRSV_PREFETCH_DEPTH 4
+#endif
+constexpr int trsv_prefetch_depth =
+    ACCBLAS_TRSV_PREFETCH_DEPTH;  // far panels in flight per wave
 
 using granule_word = unsigned long long;
 
