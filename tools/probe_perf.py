@@ -101,6 +101,8 @@ if __name__ == "__main__":
         gemv(32768, F64, F16)
         gemv(32768, F32, F16)
         gemv(24500, F64, F32)
+        gemv(32767, F64, F32)  # odd row stride: rows are only 4-byte aligned
+        gemv(32766, F64, F16)  # fp16 rows 4-byte aligned
         gemv(32768, F64, F32, incx=2)
         gemv(32768, F64, F16, incx=3)
         gemv(4096, F64, F32)
