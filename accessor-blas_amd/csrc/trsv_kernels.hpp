@@ -87,9 +87,18 @@ __device__ unsigned long long *trsv_diag_buffer;
             trsv_diag_buffer[(_block)*16 + (_slot)] = wall_clock64();       \
         }                                                                  \
     } while (false)
+#define ACCBLAS_TRSV_CYCLES(_block, _slot)                                 \
+    do {                                                                   \
+        if (lane_id() == 0 && trsv_diag_buffer != nullptr) {               \
+            trsv_diag_buffer[(_block)*16 + (_slot)] = clock64();            \
+        }                                                                  \
+    } while (false)
 #else
 #define ACCBLAS_TRSV_STAMP(_block, _slot) \
     do {                                  \
+    } while (false)
+#define ACCBLAS_TRSV_CYCLES(_block, _slot) \
+    do {                                   \
     } while (false)
 #endif
 
@@ -773,6 +782,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
                 io::load(granules, prev, raw);
             }
             ACCBLAS_TRSV_STAMP(block, 4);  // x_{b-1} observed
+            ACCBLAS_TRSV_CYCLES(block, 11);
             x_prev_lds[lane] = static_cast<ar_type>(io::decode(raw));
         }
         __syncthreads();
@@ -805,6 +815,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
             *own_addr = solution;                       // the user's vector
         }
         ACCBLAS_TRSV_STAMP(block, 5);  // published
+        ACCBLAS_TRSV_CYCLES(block, 12);
     }
     // ---- re-arm the workspace for the next solve (off the critical path) ---
     // A block is done with the workspace once its solution is published; the

@@ -129,7 +129,8 @@ int main(int argc, char **argv)
         std::printf("block: ticket  inv_done  w0_far  all_far  seen  published | hop  seen-prev_pub  pub-seen  allfar-prevprev_pub\n");
         for (unsigned b : {0u, 1u, 2u, 3u, 10u, 11u, 12u, 100u, 101u, 102u, 200u, 201u, 300u, 301u, 500u, 501u, 800u, 801u, 1000u, 1001u}) {
             if (b >= blocks) continue;
-            std::printf("%5u: staged %6.2f M_ready %6.2f |", b, us(b, 10), us(b, 6));
+            std::printf("%5u: staged %6.2f M_ready %6.2f clk %4.0f MHz |", b, us(b, 10), us(b, 6),
+                        b ? double(st[b * 16 + 12] - st[b * 16 + 11]) / (us(b, 5) - us(b, 4)) : 0.0);
             std::printf(" %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f | %6.2f %6.2f %6.2f %6.2f | seen->bar1 %5.2f matvec %5.2f bar2 %5.2f sum+pub %5.2f\n", us(b, 0), us(b, 1), us(b, 2),
                         us(b, 3), us(b, 4), us(b, 5), b ? us(b, 5) - us(b - 1, 5) : 0.0,
                         b ? us(b, 4) - us(b - 1, 5) : 0.0, us(b, 5) - us(b, 4),
