@@ -49,7 +49,7 @@ def parse_args():
     return p.parse_args()
 
 
-def cpu_baseline(oracle, ar, A_rows, lda, x, res_rows, threads):
+def cpu_baseline(oracle, ar, A_rows, lda, x, res_rows, threads, cpu_reps=12):
     """Times the oracle's host-accessor GEMV on `A_rows` (a bounded sample of the
     same workload): once on 1 thread (first 1/8 of the rows), once on all
     threads. Returns (gflops_all, gflops_one, seconds_total, res_after)."""
@@ -71,7 +71,7 @@ def cpu_baseline(oracle, ar, A_rows, lda, x, res_rows, threads):
         return time.perf_counter() - t0
 
     res_all = res_rows.copy()
-    t_all = min(run(0, rows, threads, res_all.copy()) for _ in range(2))
+    t_all = min(run(0, rows, threads, res_all.copy()) for _ in range(cpu_reps))
     res_all = res_rows.copy()
     run(0, rows, threads, res_all)  # keep one clean result for the parity check
     one_rows = max(rows // 8, 1)
@@ -343,7 +343,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
-    sample_rows = min(rows, 4096)
+    # CPU-baseline sample: half of the rows (2 GiB of fp32 on the host), swept
+    # `cpu_reps` times by all threads: about 10 core-seconds of CPU work
+    sample_rows = min(rows, 16384)
     want_cpu = world == 1 and not args.no_cpu_baseline
     A_sample = A_st[: sample_rows * lda].cpu().numpy() if want_cpu else None
     del A_st
@@ -423,8 +425,9 @@ def main():
             "single_core_value": g_one,
             "sample": f"oracle host-accessor GEMV (same kernel maths, Ar={args.ar} "
                       f"St={args.st}) on the first {sample_rows} of {rows} rows of the "
-                      f"same matrix, {threads} threads by row blocks; single_core_value "
-                      f"= 1 thread on {max(sample_rows // 8, 1)} rows",
+                      f"same matrix, {threads} threads by row blocks, min of 12 sweeps "
+                      f"(~10 core-seconds in all); single_core_value = 1 thread on "
+                      f"{max(sample_rows // 8, 1)} rows",
         }
         # the reference's own CPU path: compare + pairwise reduce on the result
         t0 = time.perf_counter()
