@@ -33,10 +33,11 @@
 //   * ONE workgroup per CU (`trsv_single_block_pad`): a second resident block
 //     would sweep on the SIMDs of the block that is on the chain;
 //   * per block: all waves stage the diagonal tile AND the last off-diagonal
-//     panel in LDS; the tile is inverted blockwise (two 32 x 32 forward
-//     substitutions by the two halves of wave 0, lanes owning columns in
-//     registers, then X10 = -X11 C X00 by all waves) instead of a Gauss-Jordan
-//     sweep through shared memory with a sync per step;
+//     panel in LDS; the tile is inverted recursively (four 16 x 16 forward
+//     substitutions by the four 16-lane groups of wave 0, lanes owning
+//     columns in registers, then two merge levels X10 = -X11 C X00 as MFMA
+//     products) instead of a Gauss-Jordan sweep through shared memory with a
+//     sync per step;
 //   * far panels (all but the last): 16-byte loads of the storage type,
 //     four panels deep in registers together with the x granules of those
 //     panels, FMA in the arithmetic type, ONE cross-lane reduction at the end;
@@ -482,74 +483,141 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
         ACCBLAS_TRSV_STAMP(block, 10);  // tile and panel staged
     }
 
-    // ---- invert the tile blockwise ----------------------------------------
-    // T = [T00 0; C T11] (32 x 32 blocks): inv = [X00 0; -X11 C X00, X11].
-    // Step 1, wave 0: lanes 0..31 own the columns of X00 = inv(T00), lanes
-    // 32..63 those of X11 = inv(T11), in registers, by forward substitution:
-    // X[i][j] = (delta_ij - sum_{k<i} T[i][k] X[k][j]) / T[i][i]. Both halves
-    // run the same instruction stream, so this costs 32 dependent rows, not 64.
-    constexpr int H = B / 2;
-    const int half = lane / H;
-    const int sub = lane % H;
-    if (wave == 0) {
-        const int off = half * H;
-        ar_type column[H];
-#pragma unroll
-        for (int i = 0; i < H; ++i) {
-            // a dependent fp64 FMA chain costs ~40 cycles per link on gfx950:
-            // four interleaved partial sums cut the row's latency by 4
-            ar_type sums[4] = {};
-#pragma unroll
-            for (int k = 0; k < i; ++k) {
-                sums[k & 3] += tile[(off + i) * ld + off + k] * column[k];
-            }
-            ar_type value = ((sub == i) ? ar_type{1} : ar_type{0}) -
-                            ((sums[0] + sums[1]) + (sums[2] + sums[3]));
-            if (!UnitDiag) {
-                value = value / tile[(off + i) * ld + off + i];
-            }
-            column[i] = value;
-        }
-        // all reads of T00 / T11 are done (same wave, program order): overwrite
-        // them with their inverses, column-major
-#pragma unroll
-        for (int i = 0; i < H; ++i) {
-            tile[(off + sub) * ld + off + i] = column[i];
-        }
-    }
-    __syncthreads();
-    // Step 2, all waves: X10 = -X11 (C X00), one column per half wave (lane =
-    // row). p = C X00[:, c] stays lane-local, is handed to the other lanes of
-    // the half through this wave's slice of partial_a, then X11 p. The result
-    // goes to tile[c * ld + H + r], the (zero) upper-right block of T in
-    // row-major terms, which nobody reads in this phase.
+    // ---- invert the tile: 16 x 16 substitutions, then two merge levels -----
+    // For T = [T00 0; C T11]: inv(T) = [X00 0; -X11 C X00, X11]. The serial
+    // part is only 16 rows long: the four 16-lane groups of wave 0 invert the
+    // four diagonal 16 x 16 blocks in one instruction stream (lanes own
+    // columns in registers, X[i][j] = (delta_ij - sum_{k<i} T[i][k] X[k][j]) /
+    // T[i][i]). The two merge levels (16 -> 32 -> 64) are small dense products
+    // on the matrix cores; the intermediate C X00 passes through LDS to get
+    // from the MFMA result layout into the operand layout. T is row-major
+    // (tile[r * ld + c]), the inverse column-major (tile[c * ld + r]): every
+    // finished block of the inverse overwrites zeros or its own source, and
+    // the off-diagonal source blocks are cleared once they have been used.
     {
-        constexpr int cols_per_wave = H / Waves;
-        static_assert(cols_per_wave % 2 == 0, "two columns per pass");
-        ar_type *hand = partial_a + wave * B + half * H;
-        for (int pass = 0; pass < cols_per_wave / 2; ++pass) {
-            const int c = wave * cols_per_wave + pass * 2 + half;
-            ar_type p[4] = {};
+        using mma = detail::mma_16x16x4<ar_type>;
+        constexpr int Q = 16;  // base block / MFMA tile edge
+        static_assert(Waves >= 8,
+                      "the merge levels use four waves and 2 x 512 words of "
+                      "the partial-sum buffers");
+        const int frag_ij = lane & 15;
+        const int frag_k = lane >> 4;
+        if (wave == 0) {
+            const int off = frag_k * Q;  // this 16-lane group's block
+            ar_type column[Q];
 #pragma unroll
-            for (int k = 0; k < H; ++k) {
-                // X00 is lower triangular: entries above the diagonal are the
-                // zeros T held there
-                p[k & 3] += tile[(H + sub) * ld + k] * tile[c * ld + k];
-            }
-            hand[sub] = (p[0] + p[1]) + (p[2] + p[3]);
-            ar_type q[4] = {};
+            for (int i = 0; i < Q; ++i) {
+                // a dependent fp64 FMA chain costs ~40 cycles per link on
+                // gfx950: four interleaved partial sums per row
+                ar_type sums[4] = {};
 #pragma unroll
-            for (int k = 0; k < H; ++k) {
-                q[k & 3] += tile[(H + k) * ld + H + sub] * hand[k];
+                for (int k = 0; k < i; ++k) {
+                    sums[k & 3] += tile[(off + i) * ld + off + k] * column[k];
+                }
+                ar_type value = ((frag_ij == i) ? ar_type{1} : ar_type{0}) -
+                                ((sums[0] + sums[1]) + (sums[2] + sums[3]));
+                if (!UnitDiag) {
+                    value = value / tile[(off + i) * ld + off + i];
+                }
+                column[i] = value;
             }
-            tile[c * ld + H + sub] = -((q[0] + q[1]) + (q[2] + q[3]));
+            // all reads of the four diagonal blocks are done (same wave,
+            // program order): overwrite them with their inverses
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                tile[(off + frag_ij) * ld + off + i] = column[i];
+            }
         }
-    }
-    __syncthreads();
-    // C (row-major, rows >= H, columns < H) is dead now; in column-major terms
-    // that region is the upper-right block of the inverse: zero
-    for (int e = threadIdx.x; e < H * H; e += Waves * wave_size) {
-        tile[(H + e / H) * ld + e % H] = ar_type{};
+        __syncthreads();
+        // level 1, waves 0 and 1: the 32 x 32 diagonal block at o = 32 * wave.
+        // P = C X00 (16 x 16 x 16), through this wave's 256 words of
+        // partial_a, then X10 = -X11 P.
+        if (wave < 2) {
+            const int o = 2 * Q * wave;
+            ar_type *scratch = partial_a + wave * Q * Q;
+            typename mma::acc_type p{};
+#pragma unroll
+            for (int k0 = 0; k0 < Q; k0 += 4) {
+                const int k = k0 + frag_k;
+                p = mma::step(tile[(o + Q + frag_ij) * ld + o + k],  // C[i][k]
+                              tile[(o + frag_ij) * ld + o + k],      // X00[k][j]
+                              p);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                scratch[mma::row(lane, reg) * Q + frag_ij] = p[reg];
+            }
+            typename mma::acc_type x10{};
+#pragma unroll
+            for (int k0 = 0; k0 < Q; k0 += 4) {
+                const int k = k0 + frag_k;
+                x10 = mma::step(
+                    tile[(o + Q + k) * ld + o + Q + frag_ij],  // X11[i][k]
+                    scratch[k * Q + frag_ij],                  // P[k][j]
+                    x10);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                // X10[r][c] of the inverse, column-major
+                tile[(o + frag_ij) * ld + o + Q + mma::row(lane, reg)] =
+                    -x10[reg];
+            }
+            // C (rows o+16.., columns o..o+15, row-major) is used up; in the
+            // inverse's layout that region is above the diagonal: zero
+#pragma unroll
+            for (int e = lane; e < Q * Q; e += wave_size) {
+                tile[(o + Q + e / Q) * ld + o + e % Q] = ar_type{};
+            }
+        }
+        __syncthreads();
+        // level 2: X10 (32 x 32) = -X11 (C X00) with the two 32 x 32 inverses.
+        // Waves 0..3 own one 16 x 16 tile each; P = C X00 is handed over
+        // through partial_a (waves 0, 1) and partial_b (waves 2, 3).
+        constexpr int H = 2 * Q;
+        const int ti = (wave >> 1) & 1;
+        const int tj = wave & 1;
+        ar_type *const scratch2 =
+            (wave < 2 ? partial_a : partial_b) + (wave & 1) * Q * Q;
+        if (wave < 4) {
+            typename mma::acc_type p{};
+            // X00 is lower triangular: rows above column tile tj are zero
+            for (int k0 = tj * Q; k0 < H; k0 += 4) {
+                const int k = k0 + frag_k;
+                p = mma::step(tile[(H + ti * Q + frag_ij) * ld + k],  // C[i][k]
+                              tile[(tj * Q + frag_ij) * ld + k],      // X00[k][j]
+                              p);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                scratch2[mma::row(lane, reg) * Q + frag_ij] = p[reg];
+            }
+        }
+        __syncthreads();
+        if (wave < 4) {
+            typename mma::acc_type x10{};
+            // X11 is lower triangular: columns beyond row tile ti are zero
+            for (int k0 = 0; k0 < (ti + 1) * Q; k0 += 4) {
+                const int k = k0 + frag_k;
+                // P tile (k / 16, tj) was written by wave 2 * (k / 16) + tj
+                const ar_type *src =
+                    ((k / Q) == 0 ? partial_a : partial_b) + tj * Q * Q;
+                x10 = mma::step(
+                    tile[(H + k) * ld + H + ti * Q + frag_ij],  // X11[i][k]
+                    src[(k % Q) * Q + frag_ij],                 // P[k][j]
+                    x10);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                tile[(tj * Q + frag_ij) * ld + H + ti * Q +
+                     mma::row(lane, reg)] = -x10[reg];
+            }
+        }
+        __syncthreads();
+        // C (rows >= 32, columns < 32, row-major) is used up: the upper-right
+        // block of the inverse is zero
+        for (int e = threadIdx.x; e < H * H; e += Waves * wave_size) {
+            tile[(H + e / H) * ld + e % H] = ar_type{};
+        }
     }
     if (wave == 0) {
         ACCBLAS_TRSV_STAMP(block, 1);  // inverse ready

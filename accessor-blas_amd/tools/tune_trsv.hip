@@ -79,13 +79,10 @@ int main(int argc, char **argv)
                      }};
     };
     std::vector<entry> entries = {
-        make("w4 vec4 2/CU", kernel::trsv<4, false, true, 4, ar_type, c_range, range>, 256, 0),
-        make("w4 vec4 1/CU", kernel::trsv<4, false, true, 4, ar_type, c_range, range>, 256, 40000),
         make("w8 vec4 2/CU", kernel::trsv<8, false, true, 4, ar_type, c_range, range>, 512, 0),
         make("w8 vec4 1/CU", kernel::trsv<8, false, true, 4, ar_type, c_range, range>, 512, 40000),
         make("w16 vec4 2/CU", kernel::trsv<16, false, true, 4, ar_type, c_range, range>, 1024, 0),
-        make("w4 vec1 2/CU", kernel::trsv<4, false, true, 1, ar_type, c_range, range>, 256, 0),
-        make("w2 vec4 2/CU", kernel::trsv<2, false, true, 4, ar_type, c_range, range>, 128, 0),
+        make("w8 vec1 1/CU", kernel::trsv<8, false, true, 1, ar_type, c_range, range>, 512, 40000),
     };
     hipEvent_t start, stop;
     CHECK(hipEventCreate(&start));
@@ -120,7 +117,7 @@ int main(int argc, char **argv)
         CHECK(hipMemset(diag, 0, size_t(blocks) * 128));
         CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_diag_buffer), &diag, sizeof(diag)));
         CHECK(hipMemcpy(x, x0, n * sizeof(st_type), hipMemcpyDeviceToDevice));
-        entries[0].run();
+        entries[1].run();
         CHECK(hipDeviceSynchronize());
         std::vector<unsigned long long> st(size_t(blocks) * 16);
         CHECK(hipMemcpy(st.data(), diag, st.size() * 8, hipMemcpyDeviceToHost));
