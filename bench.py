@@ -405,12 +405,16 @@ def main():
         with open(traffic_file) as f:
             out["roofline"]["traffic"] = json.load(f).get("gemv_vec_bytes_per_launch")
 
-    # ---- accuracy + CPU baseline on rank 0 (oracle = checker and baseline only)
-    import oracle_lib as oracle
+    # ---- accuracy on rank 0: the reference's metric sum|ref - res| / sum|ref|
+    # (gemv_benchmark.cu:101-124) against the fp64 kernel on the unrounded data
     ref_h = ref.cpu().numpy()
     got_h = first_result.cpu().numpy()
-    out["rel_err_vs_fp64"] = oracle.rel_error(ref_h, got_h.astype(np.float64))
+    out["rel_err_vs_fp64"] = float(np.abs(ref_h - got_h.astype(np.float64)).sum() /
+                                   np.abs(ref_h).sum())
     if world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline leg: the only place the oracle is used (as the
+        # baseline and as the checker of a sample of the GPU result)
+        import oracle_lib as oracle
         # the GPU box gives one-GPU jobs a share of 16 host cores
         threads = min(len(os.sched_getaffinity(0)), 16)
         A_rows = A_sample
