@@ -80,7 +80,7 @@ __device__ __forceinline__ void load_x(const XView &x, const StType *x_ptr,
  * mtx(row, col) * x(col, 0) in ArType, then
  * res(row,0) = alpha*sum (+ beta*res(row,0) if beta != 0).
  */
-template <typename Config, int Vec, bool VecX, typename ArType,
+template <typename Config, int Vec, bool VecX, bool Skew, typename ArType,
           typename MtxView, typename XView, typename ResView>
 __global__ __launch_bounds__(Config::waves *wave_size) void gemv_vec(
     ArType alpha, MtxView mtx, XView x, ArType beta, ResView res)
@@ -129,25 +129,94 @@ __global__ __launch_bounds__(Config::waves *wave_size) void gemv_vec(
     const index_type main_cols = (num_cols / iter_cols) * iter_cols;
     const index_type lane_off =
         index_type{wave_in_group} * wave_cols + index_type{lane} * Vec;
-    for (index_type c0 = 0; c0 < main_cols; c0 += iter_cols) {
-        ar_type xa[U][Vec];
-        typename packed<st_type, Vec>::type av[R][U];
+    if constexpr (Skew) {
+        // With a row pitch that is a multiple of a large power of two (the
+        // benchmark's 32768 fp32 columns = 128 KiB) all rows have the same
+        // channel and bank bits at a given column, and the loads a wave
+        // issues together - and those of the groups that walk in step with it
+        // - collide: 6.68 TB/s against 7.04-7.08 TB/s for the same matrix with
+        // 128 bytes or 4 KiB more pitch (fp64 arithmetic; the shorter fp32
+        // loop is hardly affected). So rows are skewed in time: in round t row
+        // j of a group sweeps chunk (phase + t + j) mod T, with a phase per
+        // group. Every x chunk is still loaded once per wave: a window of R
+        // chunks stays in registers, slot = position mod R. The launcher
+        // guarantees T % R == 0 and T >= R.
+        static_assert(VecX && R > 1, "skew needs a contiguous x and R > 1");
+        const index_type num_iters = main_cols / iter_cols;
+        // row groups additionally start at different chunks (5 is coprime
+        // with the power-of-two chunk counts this path is used for)
+        const index_type phase =
+            ((index_type{blockIdx.x} * Config::groups + group) * 5) % num_iters;
+        const auto wrap = [num_iters](index_type chunk) {
+            chunk -= chunk >= num_iters ? num_iters : 0;
+            chunk -= chunk >= num_iters ? num_iters : 0;
+            return chunk;
+        };
+        ar_type window[R][U][Vec];
+        const auto load_window = [&](index_type chunk, auto &slot) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const index_type c = c0 + index_type{u} * WPR * wave_cols + lane_off;
-            load_x<VecX, Vec>(x, x_ptr, c, xa[u]);
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                av[j][u] = load_packed<Vec, Config::nt>(row_ptr[j] + c);
+            for (int u = 0; u < U; ++u) {
+                const index_type c = chunk * iter_cols +
+                                     index_type{u} * WPR * wave_cols + lane_off;
+                load_x<true, Vec>(x, x_ptr, c, slot[u]);
             }
+        };
+#pragma unroll
+        for (int s = 0; s < R - 1; ++s) {
+            load_window(wrap(phase + s), window[s]);
         }
+        for (index_type t0 = 0; t0 < num_iters; t0 += R) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int k = 0; k < Vec; ++k) {
+            for (int p = 0; p < R; ++p) {
+                const index_type t = t0 + p;
+                // chunk t + R - 1 enters the slot chunk t - 1 left
+                load_window(wrap(phase + t + R - 1), window[(p + R - 1) % R]);
+                typename packed<st_type, Vec>::type av[R][U];
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    acc[j] += static_cast<ar_type>(av[j][u][k]) * xa[u][k];
+                    const index_type chunk = wrap(phase + t + j);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        av[j][u] = load_packed<Vec, Config::nt>(
+                            row_ptr[j] + chunk * iter_cols +
+                            index_type{u} * WPR * wave_cols + lane_off);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int k = 0; k < Vec; ++k) {
+#pragma unroll
+                        for (int j = 0; j < R; ++j) {
+                            acc[j] += static_cast<ar_type>(av[j][u][k]) *
+                                      window[(p + j) % R][u][k];
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        for (index_type c0 = 0; c0 < main_cols; c0 += iter_cols) {
+            ar_type xa[U][Vec];
+            typename packed<st_type, Vec>::type av[R][U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const index_type c =
+                    c0 + index_type{u} * WPR * wave_cols + lane_off;
+                load_x<VecX, Vec>(x, x_ptr, c, xa[u]);
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    av[j][u] = load_packed<Vec, Config::nt>(row_ptr[j] + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int k = 0; k < Vec; ++k) {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        acc[j] += static_cast<ar_type>(av[j][u][k]) * xa[u][k];
+                    }
                 }
             }
         }
@@ -287,6 +356,12 @@ __global__ __launch_bounds__(Waves *wave_size) void gemv_generic(
  *  with 8-16 loads in flight per lane lands within 2 % of this one. */
 using gemv_default_config = gemv_config<8, 4, 4, 2, true>;
 
+/** Shape of the time-skewed variant used for power-of-two row pitches. */
+/** Shape of the time-skewed variant (power-of-two row pitch, fp64
+ *  arithmetic): four groups of two waves, two rows each; measured against
+ *  eleven other shapes in profiles/r01_gemv_skew_ab.txt. */
+using gemv_skew_config = gemv_config<8, 2, 2, 2, true>;
+
 
 /**
  * Picks the widest vector path the operands allow and launches. Returns the
@@ -330,18 +405,40 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
     } else {
         if (lda % vec16 == 0 && is_aligned(a_ptr, 16)) {
             if (unit_x && is_aligned(x_ptr, 16)) {
-                kernel::gemv_vec<Config, vec16, true>
-                    <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+                // power-of-two row pitch and fp64 arithmetic: time-skewed
+                // rows (see the kernel); with fp32 arithmetic the plain sweep
+                // is the faster one (612 vs 622 us at 32768^2)
+                using skew = gemv_skew_config;
+                constexpr index_type skew_iter_cols =
+                    index_type{wave_size} * vec16 * skew::wpr * skew::unroll;
+                const index_type cols = mtx.length(1);
+                const index_type iters = cols / skew_iter_cols;
+                const index_type pitch_bytes =
+                    lda * static_cast<index_type>(sizeof(st_type));
+                if (std::is_same<ArType, double>::value &&
+                    pitch_bytes % (index_type{32} << 10) == 0 &&
+                    iters >= skew::rows && iters % skew::rows == 0) {
+                    const dim3 skew_grid(
+                        static_cast<unsigned>(
+                            ceildiv(rows, skew::rows_per_block)),
+                        1, 1);
+                    kernel::gemv_vec<skew, vec16, true, true>
+                        <<<skew_grid, dim3(skew::waves * wave_size), 0,
+                           stream>>>(alpha, mtx, x, beta, res);
+                } else {
+                    kernel::gemv_vec<Config, vec16, true, false>
+                        <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
+                }
             } else {
-                kernel::gemv_vec<Config, vec16, false>
+                kernel::gemv_vec<Config, vec16, false, false>
                     <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
             }
         } else if (vec8 > 1 && lda % vec8 == 0 && is_aligned(a_ptr, 8)) {
             if (unit_x && is_aligned(x_ptr, 8)) {
-                kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), true>
+                kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), true, false>
                     <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
             } else {
-                kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), false>
+                kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), false, false>
                     <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
             }
         } else {
