@@ -41,6 +41,13 @@ int validate_gemv(int64_t rows, int64_t cols, const void *A, int64_t lda,
 }  // namespace
 
 
+namespace accblas {
+inline dev::gemv_skew_mode gemv_skew_option()
+{
+    return static_cast<dev::gemv_skew_mode>(gemv_skew_option_value());
+}
+}  // namespace accblas
+
 extern "C" {
 
 
@@ -64,7 +71,7 @@ int accblas_gemv(accblas_dtype vt, int64_t rows, int64_t cols, double alpha,
         return accblas::check_hip(
             launch_gemv(static_cast<value_type>(alpha), m_view, x_view,
                         static_cast<value_type>(beta), res_view,
-                        accblas::as_stream(stream)),
+                        accblas::as_stream(stream), accblas::gemv_skew_option()),
             "gemv launch");
     });
 }
@@ -104,7 +111,8 @@ int accblas_acc_gemv(accblas_dtype ar, accblas_dtype st, int64_t rows,
             return accblas::check_hip(
                 accblas::dev::launch_gemv(static_cast<ar_type>(alpha), m_acc,
                                           x_acc, static_cast<ar_type>(beta),
-                                          res_acc, accblas::as_stream(stream)),
+                                          res_acc, accblas::as_stream(stream),
+                                          accblas::gemv_skew_option()),
                 "acc_gemv launch");
         });
     });

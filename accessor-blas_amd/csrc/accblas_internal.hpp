@@ -71,6 +71,10 @@ int dispatch_arithmetic(accblas_dtype t, F &&f)
     }
 }
 
+/** Option "gemv_skew" (accblas_set_option; defined in accblas_trsv.hip next
+ *  to the other options): 0 never, 1 automatic (default), 2 always. */
+int gemv_skew_option_value();
+
 inline hipStream_t as_stream(void *stream)
 {
     return static_cast<hipStream_t>(stream);

@@ -362,6 +362,13 @@ using gemv_default_config = gemv_config<8, 4, 4, 2, true>;
  *  eleven other shapes in profiles/r01_gemv_skew_ab.txt. */
 using gemv_skew_config = gemv_config<8, 2, 2, 2, true>;
 
+/** When the time-skewed sweep is used (option "gemv_skew" of the C ABI). */
+enum class gemv_skew_mode {
+    never = 0,
+    automatic = 1,  // fp64 arithmetic and a power-of-two row pitch (see launch_gemv)
+    always = 2      // whenever the shape allows it (measurements)
+};
+
 
 /**
  * Picks the widest vector path the operands allow and launches. Returns the
@@ -370,7 +377,8 @@ using gemv_skew_config = gemv_config<8, 2, 2, 2, true>;
 template <typename Config = gemv_default_config, typename ArType,
           typename MtxView, typename XView, typename ResView>
 hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
-                       ArType beta, const ResView &res, hipStream_t stream)
+                       ArType beta, const ResView &res, hipStream_t stream,
+                       gemv_skew_mode skew_mode = gemv_skew_mode::automatic)
 {
     using mtx_traits = view_traits<MtxView>;
     using x_traits = view_traits<XView>;
@@ -415,9 +423,22 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
                 const index_type iters = cols / skew_iter_cols;
                 const index_type pitch_bytes =
                     lda * static_cast<index_type>(sizeof(st_type));
-                if (std::is_same<ArType, double>::value &&
-                    pitch_bytes % (index_type{32} << 10) == 0 &&
-                    iters >= skew::rows && iters % skew::rows == 0) {
+                // measured (profiles/r01_gemv_skew_ab.txt): it pays for fp64
+                // arithmetic on power-of-two pitches from 16 KiB on (-16 % at
+                // 32 KiB ... -4 % at 256 KiB with fp32 storage), not for
+                // pitches like 96 or 192 KiB, not for fp32 arithmetic, and
+                // not for fp64 storage beyond 128 KiB
+                const bool power_of_two =
+                    (pitch_bytes & (pitch_bytes - 1)) == 0;
+                const bool wanted =
+                    skew_mode == gemv_skew_mode::always ||
+                    (skew_mode == gemv_skew_mode::automatic &&
+                     std::is_same<ArType, double>::value && power_of_two &&
+                     pitch_bytes >= (index_type{16} << 10) &&
+                     (sizeof(st_type) < 8 ||
+                      pitch_bytes <= (index_type{128} << 10)));
+                if (wanted && iters >= skew::rows &&
+                    iters % skew::rows == 0) {
                     const dim3 skew_grid(
                         static_cast<unsigned>(
                             ceildiv(rows, skew::rows_per_block)),

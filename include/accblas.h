@@ -81,6 +81,11 @@ size_t accblas_dtype_size(accblas_dtype t);
  *   "trsv_wide"   0 (default) / 1 = systems with n >= 4096 and 2- or 4-byte
  *                 storage use 128-row blocks (`kernel::trsv_wide`): half as many
  *                 dependent hops, the folded panel held in registers.
+ *   "gemv_skew"   1 (default) = GEMV with fp64 arithmetic and a power-of-two
+ *                 row pitch (>= 16 KiB) uses the time-skewed sweep (rows of
+ *                 a group walk the columns one chunk apart, against channel
+ *                 aliasing of power-of-two pitches); 0 = never; 2 = whenever
+ *                 the shape allows it.
  * Unknown names return ACCBLAS_ERR_INVALID_ARGUMENT. */
 int accblas_set_option(const char *name, int value);
 

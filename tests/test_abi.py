@@ -77,6 +77,15 @@ def test_argument_validation_statuses():
     assert info.value.status == -2 and "stride" in str(info.value)
 
 
+def test_options_are_validated():
+    lib = accblas.load()
+    assert lib.accblas_set_option(b"no_such_option", 1) == -2
+    assert lib.accblas_set_option(None, 1) == -2
+    assert lib.accblas_set_option(b"gemv_skew", 3) == -2
+    for name, default in ((b"gemv_skew", 1), (b"trsv_split", 0), (b"trsv_wide", 0)):
+        assert lib.accblas_set_option(name, default) == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(accblas, "_lib", None)
     monkeypatch.setattr(accblas, "LIB_PATH", "/nonexistent/libaccblas_hip.so")

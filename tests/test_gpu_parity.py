@@ -166,6 +166,38 @@ def test_gemv_vector_matrix_loads_with_strided_or_unaligned_x(gpu, st, tol, incx
     assert oracle.rel_error(want.astype(np.float64), got.astype(np.float64)) <= tol
 
 
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("ar,st", [(F64, F32), (F64, F16), (F64, F64), (F32, F32)])
+@pytest.mark.parametrize("rows,cols,lda", [(203, 4096, 4096), (130, 4096 + 37, 8192),
+                                           (64, 2048, 2048)])
+def test_gemv_plain_and_time_skewed_sweeps_match_oracle(gpu, mode, ar, st, rows, cols, lda):
+    """Option "gemv_skew": 0 = plain sweep, 2 = time-skewed sweep whenever the
+    shape allows it (power-of-two pitches use it by default with fp64 arithmetic).
+    Both must match the oracle, with ragged rows / columns, and the plain-pointer
+    kernel must stay bitwise equal to the accessor kernel in either mode."""
+    torch, accblas = gpu
+    A = make_inputs(71, rows * lda, st)
+    x = make_inputs(72, cols, st)
+    res = make_inputs(73, rows, st)
+    want = oracle.exact_gemv(ar, rows, cols, 1.25, A, lda, x, 1, -0.5, res, 1)
+    accblas.set_option("gemv_skew", mode)
+    try:
+        dres = to_dev(torch, res)
+        accblas.acc_gemv(ar, st, rows, cols, 1.25, to_dev(torch, A), lda, to_dev(torch, x), 1,
+                         -0.5, dres, 1)
+        if ar == st:
+            plain = to_dev(torch, res)
+            accblas.gemv(st, rows, cols, 1.25, to_dev(torch, A), lda, to_dev(torch, x), 1,
+                         -0.5, plain, 1)
+            torch.cuda.synchronize()
+            assert torch.equal(plain, dres)
+        torch.cuda.synchronize()
+    finally:
+        accblas.set_option("gemv_skew", 1)
+    err = oracle.rel_error(want.astype(np.float64), dres.cpu().numpy().astype(np.float64))
+    assert err <= out_tolerance(ar, st), err
+
+
 def test_gemv_empty_and_errors(gpu):
     torch, accblas = gpu
     dummy = torch.zeros(4, dtype=torch.float32, device="cuda")
