@@ -14,6 +14,9 @@
 //   * values are widened to the arithmetic type in registers, FMA'd, reduced
 //     with a 6-step 64-lane shuffle; waves of a group combine through LDS
 //     (one value per wave and row), no barrier tree;
+//   * power-of-two row pitches (the benchmark's 32768 fp32 columns) alias all
+//     rows onto the same channel / bank bits; with fp64 arithmetic the rows of
+//     a group are then skewed in time (`Skew`, see the kernel and launch_gemv);
 //   * a strided or unaligned x keeps the 16-byte matrix loads and fetches x
 //     element-wise through `operator()` (VecX = false): x is L2-resident and
 //     1/R of the matrix traffic, the stream stays the bound;
