@@ -17,6 +17,10 @@
 //   * power-of-two row pitches (the benchmark's 32768 fp32 columns) alias all
 //     rows onto the same channel / bank bits; with fp64 arithmetic the rows of
 //     a group are then skewed in time (`Skew`, see the kernel and launch_gemv);
+//   * row pitches that are not a multiple of 128 bytes (the reference's sweep:
+//     24500 fp32 columns) make every wave load straddle an extra cache line;
+//     long rows then sweep per-row grids aligned to their own line boundaries
+//     (`RowAlign`);
 //   * a strided or unaligned x keeps the 16-byte matrix loads and fetches x
 //     element-wise through `operator()` (VecX = false): x is L2-resident and
 //     1/R of the matrix traffic, the stream stays the bound;
@@ -83,8 +87,8 @@ __device__ __forceinline__ void load_x(const XView &x, const StType *x_ptr,
  * mtx(row, col) * x(col, 0) in ArType, then
  * res(row,0) = alpha*sum (+ beta*res(row,0) if beta != 0).
  */
-template <typename Config, int Vec, bool VecX, bool Skew, typename ArType,
-          typename MtxView, typename XView, typename ResView>
+template <typename Config, int Vec, bool VecX, bool Skew, bool RowAlign,
+          typename ArType, typename MtxView, typename XView, typename ResView>
 __global__ __launch_bounds__(Config::waves *wave_size) void gemv_vec(
     ArType alpha, MtxView mtx, XView x, ArType beta, ResView res)
 {
@@ -129,10 +133,75 @@ __global__ __launch_bounds__(Config::waves *wave_size) void gemv_vec(
     }
 
     // ---- main sweep: whole iterations, no bounds checks ------------------
-    const index_type main_cols = (num_cols / iter_cols) * iter_cols;
+    // (the row-aligned variant handles all columns itself)
+    const index_type main_cols =
+        RowAlign ? num_cols : (num_cols / iter_cols) * iter_cols;
     const index_type lane_off =
         index_type{wave_in_group} * wave_cols + index_type{lane} * Vec;
-    if constexpr (Skew) {
+    if constexpr (RowAlign) {
+        // Row pitch not a multiple of 128 bytes (the reference's sweep: 24500
+        // fp32 columns = 98000 bytes): every row starts somewhere else inside
+        // a cache line, and a sweep on a common column grid makes every 1 KiB
+        // wave load straddle 9 lines instead of 8 (6.7 TB/s against 6.9-7.0
+        // TB/s with 12 columns of padding). Here every row sweeps its OWN grid,
+        // shifted to its next 128-byte boundary; x is then fetched per row
+        // (from L2). The few columns before and after the aligned part are
+        // done element-wise below.
+        static_assert(VecX && !Skew, "row alignment needs a contiguous x");
+        index_type delta[R];
+        index_type max_delta = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const auto address = reinterpret_cast<std::uintptr_t>(row_ptr[j]);
+            delta[j] = static_cast<index_type>((128 - (address & 127)) & 127) /
+                       static_cast<index_type>(sizeof(st_type));
+            max_delta = delta[j] > max_delta ? delta[j] : max_delta;
+        }
+        const index_type aligned_cols =
+            num_cols > max_delta
+                ? ((num_cols - max_delta) / iter_cols) * iter_cols
+                : 0;
+        for (index_type c0 = 0; c0 < aligned_cols; c0 += iter_cols) {
+            ar_type xa[R][U][Vec];
+            typename packed<st_type, Vec>::type av[R][U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const index_type c =
+                    c0 + index_type{u} * WPR * wave_cols + lane_off;
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    av[j][u] = load_packed<Vec, Config::nt>(row_ptr[j] +
+                                                            delta[j] + c);
+                    load_x<true, Vec>(x, x_ptr, delta[j] + c, xa[j][u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int k = 0; k < Vec; ++k) {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        acc[j] +=
+                            static_cast<ar_type>(av[j][u][k]) * xa[j][u][k];
+                    }
+                }
+            }
+        }
+        // head [0, delta) and tail [delta + aligned_cols, cols) of every row
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const index_type r =
+                (row0 + j < num_rows) ? row0 + j : num_rows - 1;
+            const index_type head = delta[j] < num_cols ? delta[j] : num_cols;
+            const index_type tail_begin = head + aligned_cols;
+            const index_type count = head + (num_cols - tail_begin);
+            for (index_type e = index_type{wave_in_group} * wave_size + lane;
+                 e < count; e += WPR * wave_size) {
+                const index_type cc = e < head ? e : tail_begin + (e - head);
+                acc[j] += mtx(r, cc) * x(cc, 0);
+            }
+        }
+    } else if constexpr (Skew) {
         // With a row pitch that is a multiple of a large power of two (the
         // benchmark's 32768 fp32 columns = 128 KiB) all rows have the same
         // channel and bank bits at a given column, and the loads a wave
@@ -365,6 +434,12 @@ using gemv_default_config = gemv_config<8, 4, 4, 2, true>;
  *  eleven other shapes in profiles/r01_gemv_skew_ab.txt. */
 using gemv_skew_config = gemv_config<8, 2, 2, 2, true>;
 
+/** Shape of the variant for row pitches that are not a multiple of 128 bytes
+ *  (every row sweeps its own cache-line-aligned column grid): two groups of
+ *  four waves, four rows each, one 16-byte load per row and step; measured
+ *  against nine other shapes in profiles/r01_gemv_row_align_ab.txt. */
+using gemv_row_align_config = gemv_config<8, 4, 4, 1, true>;
+
 /** When the time-skewed sweep is used (option "gemv_skew" of the C ABI). */
 enum class gemv_skew_mode {
     never = 0,
@@ -422,6 +497,9 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
                 using skew = gemv_skew_config;
                 constexpr index_type skew_iter_cols =
                     index_type{wave_size} * vec16 * skew::wpr * skew::unroll;
+                constexpr index_type row_align_iter_cols =
+                    index_type{wave_size} * vec16 * gemv_row_align_config::wpr *
+                    gemv_row_align_config::unroll;
                 const index_type cols = mtx.length(1);
                 const index_type iters = cols / skew_iter_cols;
                 const index_type pitch_bytes =
@@ -446,23 +524,39 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
                         static_cast<unsigned>(
                             ceildiv(rows, skew::rows_per_block)),
                         1, 1);
-                    kernel::gemv_vec<skew, vec16, true, true>
+                    kernel::gemv_vec<skew, vec16, true, true, false>
                         <<<skew_grid, dim3(skew::waves * wave_size), 0,
                            stream>>>(alpha, mtx, x, beta, res);
+                } else if (pitch_bytes % 128 != 0 &&
+                           cols >= 12 * row_align_iter_cols) {
+                    // rows start inside cache lines: per-row aligned grids
+                    // (24500^2 fp32: 357 -> 339 us; below ~12 steps per row
+                    // the element-wise head and tail cost more than the
+                    // alignment gains)
+                    using aligned = gemv_row_align_config;
+                    const dim3 aligned_grid(
+                        static_cast<unsigned>(
+                            ceildiv(rows, aligned::rows_per_block)),
+                        1, 1);
+                    kernel::gemv_vec<aligned, vec16, true, false, true>
+                        <<<aligned_grid, dim3(aligned::waves * wave_size), 0,
+                           stream>>>(alpha, mtx, x, beta, res);
                 } else {
-                    kernel::gemv_vec<Config, vec16, true, false>
+                    kernel::gemv_vec<Config, vec16, true, false, false>
                         <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
                 }
             } else {
-                kernel::gemv_vec<Config, vec16, false, false>
+                kernel::gemv_vec<Config, vec16, false, false, false>
                     <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
             }
         } else if (vec8 > 1 && lda % vec8 == 0 && is_aligned(a_ptr, 8)) {
             if (unit_x && is_aligned(x_ptr, 8)) {
-                kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), true, false>
+                kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), true, false,
+                                 false>
                     <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
             } else {
-                kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), false, false>
+                kernel::gemv_vec<Config, (vec8 > 1 ? vec8 : 2), false, false,
+                                 false>
                     <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);
             }
         } else {

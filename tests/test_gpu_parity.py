@@ -64,6 +64,8 @@ GEMV_SHAPES = [
     (130, 1027, 1031, 0),  # lda odd -> generic path
     (200, 512, 520, 1),    # misaligned base -> narrower / generic path
     (3, 70000, 70000, 0),  # few long rows
+    (37, 13000, 13004, 0),  # pitch not a multiple of 128 bytes: per-row aligned grids
+    (9, 26001, 26004, 0),
 ]
 
 
