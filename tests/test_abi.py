@@ -145,3 +145,28 @@ def test_comm_prototypes_and_host_side_validation():
     assert lib.accblas_comm_acc_gemv(None, 2, 1, 4, 4, 1.0, dummy, 4, dummy, 1, 0.0,
                                      dummy, 1, None, None) == -3
     assert lib.accblas_comm_destroy(None) == 0
+
+
+def test_shard_bounds_properties():
+    """Property test of the partition both multi-GPU layers use: the pieces tile
+    [0, n) in rank order, sizes differ by at most one (or by less than `align`
+    at aligned interior edges), and the C and Python implementations agree."""
+    from hypothesis import given, settings, strategies as st
+    from accblas import comm, multi_gpu
+
+    @settings(max_examples=200, deadline=None)
+    @given(n=st.integers(0, 1 << 40), world=st.integers(1, 64),
+           align=st.sampled_from([1, 2, 8, 64]))
+    def check(n, world, align):
+        pieces = [comm.shard_bounds(n, world, r, align) for r in range(world)]
+        assert pieces[0][0] == 0 and pieces[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
+        assert all(lo <= hi for lo, hi in pieces)
+        if align == 1:
+            assert pieces == [multi_gpu.shard_bounds(n, world, r) for r in range(world)]
+            sizes = [hi - lo for lo, hi in pieces]
+            assert max(sizes) - min(sizes) <= 1
+        else:
+            assert all(p[1] % align == 0 for p in pieces[:-1])
+
+    check()

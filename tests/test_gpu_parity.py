@@ -534,3 +534,17 @@ def test_device_convert_is_the_reference_static_cast(gpu, src, dst):
     got = d_dst.cpu().numpy()
     bits = {F16: np.uint16, F32: np.uint32, F64: np.uint64}[dst]
     assert np.array_equal(got.view(bits), want.view(bits))
+
+
+def test_trsv_soak_random_solves_on_two_streams(gpu):
+    """A short run of tools/soak_trsv.py: hundreds of back-to-back solves of
+    random sizes / uplo / storage types on two streams, helper word and residuals
+    checked along the way (the self re-arming workspace must never go stale)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools",
+                        "soak_trsv.py")
+    spec = importlib.util.spec_from_file_location("soak_trsv", path)
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    module.main(iterations=800, seed=11)
