@@ -359,9 +359,9 @@ struct granule_io {
  * `:725-893` (upper): x_b = inv(T_bb) * (x_b - sum_{c<b} A_bc x_c), all in
  * ArType, x stored as StType and re-read by later blocks as stored.
  */
-template <int Waves, bool Upper, bool UnitDiag, int Vec, typename ArType,
-          typename MtxView, typename XView>
-__global__ __launch_bounds__(Waves *wave_size) void trsv(
+template <int Waves, bool Upper, bool UnitDiag, int Vec, bool Relay,
+          typename ArType, typename MtxView, typename XView>
+__global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     MtxView mtx, XView x, std::uint32_t *helper, trsv_session session)
 {
     using ar_type = decltype(mtx(0, 0) * x(0, 0));
@@ -388,13 +388,27 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     __shared__ ar_type partial_b[Waves * B];
     __shared__ ar_type x_prev_lds[B];
     __shared__ std::int32_t shared_block;
+    constexpr int XK = 16;  // panels of x in the LDS ring of the far sweep
+    __shared__ ar_type x_ring[XK][B];
+    __shared__ volatile std::int32_t x_ring_tag[XK];       // panel index + 1
+    __shared__ volatile std::int32_t sweep_progress[Waves];  // panels consumed
 
     const int lane = lane_id();
     const int wave = wave_id();
+    // waves 0 .. Waves-1 work on the block's rows; wave `Waves` is the loader:
+    // it feeds the solutions of earlier blocks into LDS for the far sweep
+    // (see there) and otherwise only takes part in the barriers
+    const bool worker = !Relay || wave < Waves;
     const index_type n = mtx.length(0);
 
     granule_word *const granules = session.granules;
     __shared__ std::uint32_t shared_epoch;
+    if (threadIdx.x < XK) {
+        x_ring_tag[threadIdx.x] = 0;
+    }
+    if (threadIdx.x < Waves) {
+        sweep_progress[threadIdx.x] = 0;
+    }
     if (threadIdx.x == 0) {
         // the previous solve on this workspace finished before this kernel
         // started (stream order), so the epoch is stable for the whole solve
@@ -446,7 +460,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     // ---- diagonal tile and last panel -> LDS (a wave reads one row) -------
     // every load of the wave's rows is issued before the first LDS store, so
     // the staging costs one memory latency, not one per row
-    {
+    if (worker) {
         constexpr int RS = B / Waves;  // rows a wave stages
         ar_type diag_value[RS];
         ar_type panel_value[RS];
@@ -615,7 +629,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
         __syncthreads();
         // C (rows >= 32, columns < 32, row-major) is used up: the upper-right
         // block of the inverse is zero
-        for (int e = threadIdx.x; e < H * H; e += Waves * wave_size) {
+        for (int e = threadIdx.x; e < H * H; e += blockDim.x) {
             tile[(H + e / H) * ld + e % H] = ar_type{};
         }
     }
@@ -660,7 +674,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
             int ti, tj;
             tile_of(t, ti, tj);
             typename mma::acc_type acc{};
-            for (int pass = 0; pass <= ti; ++pass) {
+            for (int pass = 0; worker && pass <= ti; ++pass) {
                 // all eight operand loads of a pass are issued before the
                 // first of its four dependent MFMAs
                 ar_type a[4];
@@ -685,8 +699,10 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
             tile_of(t, ti, tj);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                panel[(tj * 16 + frag_ij) * ld + ti * 16 +
-                      mma::row(lane, reg)] = m_tile[t][reg];
+                if (worker) {
+                    panel[(tj * 16 + frag_ij) * ld + ti * 16 +
+                          mma::row(lane, reg)] = m_tile[t][reg];
+                }
             }
         }
         // readers of M wait behind the barrier that ends the far sweep
@@ -701,9 +717,22 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     const index_type far_end = block - 1;  // panels [0, far_end)
     const int row_in_inst = lane / LPR;
     const int col_group = lane % LPR;
+    // x reaches the workers through LDS: only the loader wave reads the
+    // granules of a panel (lane = element, ONE load instruction per panel
+    // and workgroup, several panels in flight), decodes them into a ring of
+    // XK panels and tags the slot; the workers wait on the LDS tag. Every
+    // worker polling every granule itself cost as many bytes as the matrix
+    // (8-byte uncached loads, 16 KB per panel and workgroup): at n = 65536
+    // that second stream, not the chain, set the pace (2 x 3.8 TB/s through
+    // the fabric). The loader has no matrix loads of its own, so it runs
+    // ahead of the workers by up to XK panels and they stay independent of
+    // each other.
+    // Small systems keep the direct variant (Relay = false, no loader wave,
+    // every worker polls the granules it needs): the detour costs ~0.1 us per
+    // hop when the chain is all there is (n = 8192: 172 vs 190 us).
     struct stage {
         st_type a[NI][Vec];
-        granule_word xraw[Vec][io::words];
+        granule_word xraw[Relay ? 1 : Vec][io::words];  // direct variant only
     };
     const st_type *row_ptr[NI];
 #pragma unroll
@@ -729,9 +758,11 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
                 s.a[k][0] = row_ptr[k][mem_col];
             }
         }
+        if constexpr (!Relay) {
 #pragma unroll
-        for (int e = 0; e < Vec; ++e) {
-            io::load(granules, first_col + e, s.xraw[e]);
+            for (int e = 0; e < Vec; ++e) {
+                io::load(granules, first_col + e, s.xraw[e]);
+            }
         }
     };
     ar_type acc[NI];
@@ -741,26 +772,42 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     }
     unsigned int spins = 0;
     const auto consume = [&](index_type cb, stage &s) {
-        const index_type first_col = cb * B + col_group * Vec;
-        while (true) {
-            bool ok = true;
-#pragma unroll
-            for (int e = 0; e < Vec; ++e) {
-                ok = ok && io::ready(s.xraw[e], epoch);
-            }
-            if (__all(ok) || detail::spin_expired(spins, helper)) {
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-            for (int e = 0; e < Vec; ++e) {
-                io::load(granules, first_col + e, s.xraw[e]);
-            }
-        }
+        const int slot = static_cast<int>(cb % XK);
+        const std::int32_t wanted = static_cast<std::int32_t>(cb) + 1;
         ar_type xv[Vec];
+        if constexpr (!Relay) {
+            const index_type first_col = cb * B + col_group * Vec;
+            while (true) {
+                bool ok = true;
 #pragma unroll
-        for (int e = 0; e < Vec; ++e) {
-            xv[e] = static_cast<ar_type>(io::decode(s.xraw[e]));
+                for (int e = 0; e < Vec; ++e) {
+                    ok = ok && io::ready(s.xraw[e], epoch);
+                }
+                if (__all(ok) || detail::spin_expired(spins, helper)) {
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int e = 0; e < Vec; ++e) {
+                    io::load(granules, first_col + e, s.xraw[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < Vec; ++e) {
+                xv[e] = static_cast<ar_type>(io::decode(s.xraw[e]));
+            }
+        } else {
+            while (x_ring_tag[slot] != wanted &&
+                   !detail::spin_expired(spins, helper)) {
+                // eight waves spinning on LDS at full rate would take issue
+                // slots from the loader on the same SIMDs
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int e = 0; e < Vec; ++e) {
+                xv[e] = x_ring[slot][col_group * Vec + e];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
@@ -772,8 +819,58 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
                           xv[Upper ? Vec - 1 - e : e];
             }
         }
+        // this wave is done with the slot (its LDS reads above were issued
+        // first and LDS serves a wave's operations in order)
+        if (Relay && lane == 0) {
+            sweep_progress[wave] = wanted;
+        }
     };
-    if (far_end > 0) {
+    if (!worker) {
+        // ---- loader wave: granules of panels [0, far_end) -> LDS ring -------
+        constexpr int L = 8;  // panels whose granule loads are in flight
+        static_assert(XK >= 2 * L, "room for the loader to run ahead");
+        const index_type relayed = far_end;
+        for (index_type p0 = 0; p0 < relayed; p0 += L) {
+            granule_word raw[L][io::words];
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                if (p0 + i < relayed) {
+                    io::load(granules, (p0 + i) * B + lane, raw[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const index_type p = p0 + i;
+                if (p < relayed) {
+                    const int slot = static_cast<int>(p % XK);
+                    const std::int32_t wanted = static_cast<std::int32_t>(p) + 1;
+                    // the slot still holds panel p - XK: wait until every
+                    // worker has read it
+                    if (p >= XK) {
+                        const std::int32_t need = wanted - XK;
+                        while (!__all(lane >= Waves ||
+                                      sweep_progress[lane < Waves ? lane : 0] >=
+                                          need) &&
+                               !detail::spin_expired(spins, helper)) {
+                        }
+                    }
+                    while (!__all(io::ready(raw[i], epoch)) &&
+                           !detail::spin_expired(spins, helper)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        io::load(granules, p * B + lane, raw[i]);
+                    }
+                    x_ring[slot][lane] =
+                        static_cast<ar_type>(io::decode(raw[i]));
+                    // LDS operations of one wave complete in order: data,
+                    // then the tag
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) {
+                        x_ring_tag[slot] = wanted;
+                    }
+                }
+            }
+        }
+    } else if (far_end > 0) {
         // ring of `depth` stages: the matrix data of the next `depth` panels
         // is always in flight (it does not depend on x); each hop of the
         // front triggers one new 16 KB panel load per block, and its latency
@@ -803,7 +900,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
     for (int k = 0; k < NI; ++k) {
         const ar_type total = group_all_reduce<LPR>(
             acc[k], [](ar_type a, ar_type b) { return a + b; });
-        if (col_group == 0) {
+        if (worker && col_group == 0) {
             const int r = wave * RW + k * Vec + row_in_inst;
             correction[r] = (base + r < n) ? total : ar_type{};
         }
@@ -823,7 +920,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
         ACCBLAS_TRSV_STAMP(block, 3);  // all waves finished the far sweep
     }
     ar_type rhs = own_valid ? own_rhs - correction[lane] : ar_type{};
-    {
+    if (worker) {
         // every wave holds the full right-hand side (lane = row); entry
         // wave*CW + j of it multiplies column wave*CW + j of the inverse
         ar_type part[4] = {};
@@ -857,14 +954,16 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
         if (wave == 0) {
             ACCBLAS_TRSV_STAMP(block, 7);  // x_{b-1} handed to all waves
         }
-        ar_type part[4] = {};
+        if (worker) {
+            ar_type part[4] = {};
 #pragma unroll
-        for (int j = 0; j < CW; ++j) {
-            part[j & 3] += panel[(wave_u * CW + j) * ld + lane] *
-                           x_prev_lds[wave_u * CW + j];
+            for (int j = 0; j < CW; ++j) {
+                part[j & 3] += panel[(wave_u * CW + j) * ld + lane] *
+                               x_prev_lds[wave_u * CW + j];
+            }
+            partial_a[wave_u * B + lane] =
+                (part[0] + part[1]) + (part[2] + part[3]);
         }
-        partial_a[wave_u * B + lane] =
-            (part[0] + part[1]) + (part[2] + part[3]);
         if (wave == 0) {
             ACCBLAS_TRSV_STAMP(block, 8);  // wave 0 mat-vec share done
         }
@@ -901,7 +1000,7 @@ __global__ __launch_bounds__(Waves *wave_size) void trsv(
         if (next_epoch == 0) {
             // 2^32 solves on this workspace: stale tags could repeat
             for (index_type i = threadIdx.x; i < session.capacity_words;
-                 i += Waves * wave_size) {
+                 i += blockDim.x) {
                 __hip_atomic_store(granules + i, granule_word{0},
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -944,14 +1043,29 @@ template <typename ArType, int Waves>
 constexpr unsigned trsv_single_block_pad()
 {
     constexpr std::size_t B = trsv_tile;
+    // tile, panel, correction, x_prev, the two partial-sum buffers, the x ring
+    // of the far sweep (8 panels) and a few words of bookkeeping
     constexpr std::size_t static_bytes =
-        sizeof(ArType) * (2 * B * (B + 1) + 2 * B + 2 * Waves * B) + 16;
+        sizeof(ArType) * (2 * B * (B + 1) + 2 * B + 2 * Waves * B + 16 * B) +
+        192;
     constexpr std::size_t needed = 160 * 1024 / 2 + 2048;
     return static_bytes >= needed
                ? 0u
                : static_cast<unsigned>(needed - static_bytes);
 }
 
+
+/** When the far sweep's x goes through the loader wave and LDS (measured,
+ *  profiles/r01_trsv_relay_ab.txt). ACCBLAS_TRSV_RELAY_MODE: 0 never, 1 by
+ *  size, 2 always (A/B builds). */
+#ifndef ACCBLAS_TRSV_RELAY_MODE
+#define ACCBLAS_TRSV_RELAY_MODE 1
+#endif
+#ifndef ACCBLAS_TRSV_RELAY_MIN_N
+#define ACCBLAS_TRSV_RELAY_MIN_N 20000
+#endif
+constexpr int trsv_relay_mode = ACCBLAS_TRSV_RELAY_MODE;
+constexpr index_type trsv_relay_min_n = ACCBLAS_TRSV_RELAY_MIN_N;
 
 /** Workgroups (= tickets) a solve of n unknowns launches. */
 inline unsigned trsv_num_blocks(index_type n)
@@ -979,18 +1093,38 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     constexpr int waves = trsv_waves;
     constexpr int vec16 = 16 / sizeof(st_type);
     const dim3 grid(trsv_num_blocks(n), 1, 1);
-    const dim3 block(waves * wave_size, 1, 1);
     constexpr unsigned pad = trsv_single_block_pad<ArType, waves>();
+    // x through the loader wave and LDS (one more wave per workgroup) where
+    // it was measured to pay (profiles/r01_trsv_relay_ab.txt): the granule
+    // stream it removes weighs 8 bytes per element and worker, so it wins
+    // big for fp16 storage (+22-48 %), for fp64 storage from n = 20000 on
+    // (+10-20 %) and a little for fp32 arithmetic; fp64 arithmetic on fp32
+    // storage is faster without the detour at every size up to 16384 and
+    // within noise beyond
+    constexpr bool half_storage = sizeof(st_type) == 2;
+    constexpr bool double_storage = sizeof(st_type) == 8;
+    constexpr bool float_arithmetic = std::is_same<ArType, float>::value;
+    const bool by_rule = half_storage || float_arithmetic ||
+                         (double_storage && n >= trsv_relay_min_n);
+    const bool relay =
+        trsv_relay_mode == 2 || (trsv_relay_mode == 1 && by_rule);
+    const dim3 block((waves + (relay ? 1 : 0)) * wave_size, 1, 1);
     const bool vec_ok = is_aligned(mtx_traits::data(mtx), 16) &&
                         mtx_traits::stride(mtx) % vec16 == 0 &&
                         (!upper || n % vec16 == 0);
-#define ACCBLAS_TRSV_LAUNCH(_upper, _unit)                                     \
+#define ACCBLAS_TRSV_LAUNCH_RELAY(_upper, _unit, _relay)                       \
     if (vec_ok) {                                                              \
-        kernel::trsv<waves, _upper, _unit, vec16, ArType>                      \
+        kernel::trsv<waves, _upper, _unit, vec16, _relay, ArType>              \
             <<<grid, block, pad, stream>>>(mtx, x, helper, session);           \
     } else {                                                                   \
-        kernel::trsv<waves, _upper, _unit, 1, ArType>                          \
+        kernel::trsv<waves, _upper, _unit, 1, _relay, ArType>                  \
             <<<grid, block, pad, stream>>>(mtx, x, helper, session);           \
+    }
+#define ACCBLAS_TRSV_LAUNCH(_upper, _unit)                                     \
+    if (relay) {                                                               \
+        ACCBLAS_TRSV_LAUNCH_RELAY(_upper, _unit, true)                         \
+    } else {                                                                   \
+        ACCBLAS_TRSV_LAUNCH_RELAY(_upper, _unit, false)                        \
     }
     if (upper) {
         if (unit_diag) {
@@ -1006,6 +1140,7 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
         }
     }
 #undef ACCBLAS_TRSV_LAUNCH
+#undef ACCBLAS_TRSV_LAUNCH_RELAY
     return hipGetLastError();
 }
 

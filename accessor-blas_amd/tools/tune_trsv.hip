@@ -79,10 +79,11 @@ int main(int argc, char **argv)
                      }};
     };
     std::vector<entry> entries = {
-        make("w8 vec4 2/CU", kernel::trsv<8, false, true, 4, ar_type, c_range, range>, 512, 0),
-        make("w8 vec4 1/CU", kernel::trsv<8, false, true, 4, ar_type, c_range, range>, 512, 40000),
-        make("w16 vec4 2/CU", kernel::trsv<16, false, true, 4, ar_type, c_range, range>, 1024, 0),
-        make("w8 vec1 1/CU", kernel::trsv<8, false, true, 1, ar_type, c_range, range>, 512, 40000),
+        // 8 worker waves + the loader wave = 576 threads
+        make("direct 2/CU", kernel::trsv<8, false, true, 4, false, ar_type, c_range, range>, 512, 0),
+        make("direct 1/CU", kernel::trsv<8, false, true, 4, false, ar_type, c_range, range>, 512, 40000),
+        make("relay 1/CU", kernel::trsv<8, false, true, 4, true, ar_type, c_range, range>, 576, 40000),
+        make("direct vec1 1/CU", kernel::trsv<8, false, true, 1, false, ar_type, c_range, range>, 512, 40000),
     };
     hipEvent_t start, stop;
     CHECK(hipEventCreate(&start));
