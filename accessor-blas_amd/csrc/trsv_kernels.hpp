@@ -1039,15 +1039,18 @@ constexpr std::size_t trsv_workspace_bytes(index_type n)
  * 2.65 ms instead of 2.32 ms and fp64 storage at n = 24000 1.82 ms instead of
  * 0.91 ms (profiles/r01_trsv_occupancy.txt).
  */
-template <typename ArType, int Waves>
+template <typename ArType, int Waves, bool Relay>
 constexpr unsigned trsv_single_block_pad()
 {
     constexpr std::size_t B = trsv_tile;
-    // tile, panel, correction, x_prev, the two partial-sum buffers, the x ring
-    // of the far sweep (8 panels) and a few words of bookkeeping
+    // tile, panel, correction, x_prev, the two partial-sum buffers, a few
+    // words of bookkeeping and, in the relay variant only (the compiler drops
+    // it from the direct one), the x ring of the far sweep (16 panels); an
+    // underestimate is harmless (more padding), an overestimate is not
     constexpr std::size_t static_bytes =
-        sizeof(ArType) * (2 * B * (B + 1) + 2 * B + 2 * Waves * B + 16 * B) +
-        192;
+        sizeof(ArType) *
+            (2 * B * (B + 1) + 2 * B + 2 * Waves * B + (Relay ? 16 * B : 0)) +
+        16;
     constexpr std::size_t needed = 160 * 1024 / 2 + 2048;
     return static_bytes >= needed
                ? 0u
@@ -1062,7 +1065,7 @@ constexpr unsigned trsv_single_block_pad()
 #define ACCBLAS_TRSV_RELAY_MODE 1
 #endif
 #ifndef ACCBLAS_TRSV_RELAY_MIN_N
-#define ACCBLAS_TRSV_RELAY_MIN_N 20000
+#define ACCBLAS_TRSV_RELAY_MIN_N 17000
 #endif
 constexpr int trsv_relay_mode = ACCBLAS_TRSV_RELAY_MODE;
 constexpr index_type trsv_relay_min_n = ACCBLAS_TRSV_RELAY_MIN_N;
@@ -1093,14 +1096,13 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     constexpr int waves = trsv_waves;
     constexpr int vec16 = 16 / sizeof(st_type);
     const dim3 grid(trsv_num_blocks(n), 1, 1);
-    constexpr unsigned pad = trsv_single_block_pad<ArType, waves>();
     // x through the loader wave and LDS (one more wave per workgroup) where
     // it was measured to pay (profiles/r01_trsv_relay_ab.txt): the granule
     // stream it removes weighs 8 bytes per element and worker, so it wins
-    // big for fp16 storage (+22-48 %), for fp64 storage from n = 20000 on
-    // (+10-20 %) and a little for fp32 arithmetic; fp64 arithmetic on fp32
-    // storage is faster without the detour at every size up to 16384 and
-    // within noise beyond
+    // big for fp16 storage (-20...-27 % time), for fp64 storage once there
+    // are more blocks than CUs (-8...-15 %) and a little for fp32 arithmetic;
+    // fp64 arithmetic on fp32 storage is faster without the detour at every
+    // size
     constexpr bool half_storage = sizeof(st_type) == 2;
     constexpr bool double_storage = sizeof(st_type) == 8;
     constexpr bool float_arithmetic = std::is_same<ArType, float>::value;
@@ -1109,6 +1111,8 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     const bool relay =
         trsv_relay_mode == 2 || (trsv_relay_mode == 1 && by_rule);
     const dim3 block((waves + (relay ? 1 : 0)) * wave_size, 1, 1);
+    const unsigned pad = relay ? trsv_single_block_pad<ArType, waves, true>()
+                               : trsv_single_block_pad<ArType, waves, false>();
     const bool vec_ok = is_aligned(mtx_traits::data(mtx), 16) &&
                         mtx_traits::stride(mtx) % vec16 == 0 &&
                         (!upper || n % vec16 == 0);
