@@ -222,3 +222,37 @@ def test_trsv_alternative_kernels_match_oracle(gpu, option, upper, unit, ar, st)
     torch.cuda.synchronize()
     accblas.set_option(option, 0)
     assert torch.equal(dx, dx2)
+
+
+@pytest.mark.parametrize("ar,st,n,tol", [
+    (F64, F64, 18000, 1e-12),   # fp64 storage beyond 17000 unknowns: loader-wave variant
+    (F64, F64, 16001, 1e-12),   # just below: direct variant, ragged last block
+    (F32, F32, 20011, 2e-4),    # fp32 arithmetic: loader-wave variant, ragged
+    (F64, F16, 20000, 2e-2),    # fp16 storage: loader-wave variant
+])
+@pytest.mark.parametrize("upper", [False, True])
+def test_trsv_loader_wave_variant_residuals(gpu, ar, st, n, tol, upper):
+    """More row blocks than CUs, through both far-sweep variants (x polled by every
+    worker / fed through the loader wave and LDS): residual of sampled rows, no
+    expired spin. The fp16 case needs a vector-aligned n for the upper path."""
+    torch, accblas = gpu
+    dtype = accblas.torch_dtype(st)
+    T = uniform(torch, n * n, torch.float32, 21, scale=1.0 / n ** 0.5).to(dtype)
+    b = uniform(torch, n, torch.float32, 22).to(dtype)
+    x = b.clone()
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    accblas.acc_trsv(ar, st, accblas.UPPER if upper else accblas.LOWER, accblas.UNIT, n, T,
+                     n, x, 1, helper)
+    torch.cuda.synchronize()
+    assert int(helper[0].item()) & 0xffffffff == 0xffffffff
+    assert bool(torch.isfinite(x.float()).all())
+    rows = torch.cat([torch.arange(0, 70, device="cuda"),
+                      torch.randint(0, n, (200,), device="cuda"),
+                      torch.arange(n - 70, n, device="cuda")])
+    Tr = T.view(n, n)[rows].double()
+    cols = torch.arange(n, device="cuda")
+    mask = cols[None, :] > rows[:, None] if upper else cols[None, :] < rows[:, None]
+    Tr = torch.where(mask, Tr, torch.zeros_like(Tr))
+    resid = Tr @ x.double() + x.double()[rows] - b.double()[rows]
+    rel = float(resid.abs().sum() / b.double()[rows].abs().sum())
+    assert rel <= tol, rel
