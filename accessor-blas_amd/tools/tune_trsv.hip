@@ -51,6 +51,7 @@ int main(int argc, char **argv)
 {
     const long n = argc > 1 ? std::atol(argv[1]) : 65536;
     const int rounds = argc > 2 ? std::atoi(argv[2]) : 5;
+    const int stamp_entry = argc > 3 ? std::atoi(argv[3]) : 1;  // variant to stamp
     st_type *A, *x, *x0;
     std::uint32_t *helper;
     granule_word *granules;
@@ -118,7 +119,7 @@ int main(int argc, char **argv)
         CHECK(hipMemset(diag, 0, size_t(blocks) * 128));
         CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_diag_buffer), &diag, sizeof(diag)));
         CHECK(hipMemcpy(x, x0, n * sizeof(st_type), hipMemcpyDeviceToDevice));
-        entries[1].run();
+        entries[stamp_entry].run();
         CHECK(hipDeviceSynchronize());
         std::vector<unsigned long long> st(size_t(blocks) * 16);
         CHECK(hipMemcpy(st.data(), diag, st.size() * 8, hipMemcpyDeviceToHost));
