@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,7 +19,10 @@ struct accblas_comm {
     int world_size;
     int rank;
     int device;
-    void *scalar;  // 16-byte device slot: partial / reduced dot in `ar`
+    void *scalar;  // 16-byte device slot: [0, 8) this rank's partial dot in
+                   // `ar`, [8, 16) the reduced one when a cast must follow
+    bool always_collective;  // ACCBLAS_COMM_FORCE_COLLECTIVE=1: a world of one
+                             // rank still runs the collectives (tests)
 };
 
 
@@ -26,6 +30,22 @@ namespace {
 
 
 thread_local std::string last_error;
+
+// Calls bracketed by accblas_comm_group_begin/_end (one host thread driving
+// several communicators): RCCL only RECORDS a collective issued inside a group
+// and enqueues it at ncclGroupEnd, so anything that must run after the
+// collective on the same stream is recorded here and enqueued by
+// accblas_comm_group_end, after ncclGroupEnd.
+struct pending_cast {
+    int device;
+    accblas_dtype dst_t;
+    void *dst;
+    accblas_dtype src_t;
+    const void *src;
+    void *stream;
+};
+thread_local int group_depth = 0;
+thread_local std::vector<pending_cast> pending_casts;
 
 int fail(int code, const std::string &message)
 {
@@ -109,7 +129,9 @@ int make_comm(accblas_comm **out, ncclComm_t raw, int world_size, int rank,
     if (status != ACCBLAS_OK) {
         return status;
     }
-    *out = new accblas_comm{raw, world_size, rank, device, scalar};
+    const char *force = std::getenv("ACCBLAS_COMM_FORCE_COLLECTIVE");
+    *out = new accblas_comm{raw, world_size, rank, device, scalar,
+                            force != nullptr && force[0] == '1'};
     return ACCBLAS_OK;
 }
 
@@ -274,13 +296,40 @@ int accblas_comm_device(const accblas_comm *comm, int *device)
 
 int accblas_comm_group_begin(void)
 {
-    return check_rccl(ncclGroupStart(), "ncclGroupStart");
+    const int status = check_rccl(ncclGroupStart(), "ncclGroupStart");
+    if (status == ACCBLAS_OK) {
+        ++group_depth;
+    }
+    return status;
 }
 
 int accblas_comm_group_end(void)
 {
-    return check_rccl(ncclGroupEnd(), "ncclGroupEnd");
+    int status = check_rccl(ncclGroupEnd(), "ncclGroupEnd");
+    if (group_depth > 0) {
+        --group_depth;
+    }
+    if (group_depth > 0) {
+        return status;
+    }
+    // the collectives of the group are enqueued now: what has to follow them
+    // in stream order can be
+    for (const pending_cast &cast : pending_casts) {
+        if (status != ACCBLAS_OK) {
+            break;
+        }
+        device_guard guard(cast.device);
+        status = guard.status();
+        if (status == ACCBLAS_OK) {
+            status = check_local(accblas_convert(cast.dst_t, cast.dst,
+                                                 cast.src_t, cast.src, 1,
+                                                 cast.stream));
+        }
+    }
+    pending_casts.clear();
+    return status;
 }
+
 
 int accblas_shard_bounds(int64_t n, int world_size, int rank, int64_t align,
                          int64_t *begin, int64_t *end)
@@ -336,25 +385,39 @@ int accblas_comm_acc_dot(accblas_comm *comm, accblas_handle *handle,
     if (guard.status() != ACCBLAS_OK) {
         return guard.status();
     }
+    const bool collective = comm->world_size > 1 || comm->always_collective;
+    void *const partial = comm->scalar;
+    void *const reduced = static_cast<char *>(comm->scalar) + 8;
+    if (!collective) {
+        // a world of one rank: the chunk dot writes the result directly
+        return check_local(accblas_acc_dot(handle, ar, st, res_t, n_local, x,
+                                           incx, y, incy, res, stream));
+    }
     // chunk -> device scalar in the ARITHMETIC type (an empty chunk yields 0)
     int status = check_local(accblas_acc_dot(handle, ar, st, ar, n_local, x,
-                                             incx, y, incy, comm->scalar,
-                                             stream));
+                                             incx, y, incy, partial, stream));
     if (status != ACCBLAS_OK) {
         return status;
     }
-    if (comm->world_size > 1) {
-        status = check_rccl(
-            ncclAllReduce(comm->scalar, comm->scalar, 1, wire, ncclSum,
-                          comm->comm, static_cast<hipStream_t>(stream)),
-            "ncclAllReduce");
-        if (status != ACCBLAS_OK) {
-            return status;
-        }
+    // Stream order: chunk dot -> all-reduce -> (cast). When the result type
+    // IS the arithmetic type the all-reduce writes `res` itself and nothing
+    // follows it. Otherwise the cast must come after the exchange; inside a
+    // group (accblas_comm_group_begin) the all-reduce is only enqueued by
+    // ncclGroupEnd, so the cast is deferred to accblas_comm_group_end.
+    const bool direct = res_t == ar;
+    status = check_rccl(
+        ncclAllReduce(partial, direct ? res : reduced, 1, wire, ncclSum,
+                      comm->comm, static_cast<hipStream_t>(stream)),
+        "ncclAllReduce");
+    if (status != ACCBLAS_OK || direct) {
+        return status;
     }
-    // the cast to the result type comes after the exchange
-    return check_local(
-        accblas_convert(res_t, res, ar, comm->scalar, 1, stream));
+    if (group_depth > 0) {
+        pending_casts.push_back(
+            pending_cast{comm->device, res_t, res, ar, reduced, stream});
+        return ACCBLAS_OK;
+    }
+    return check_local(accblas_convert(res_t, res, ar, reduced, 1, stream));
 }
 
 int accblas_comm_acc_gemv(accblas_comm *comm, accblas_dtype ar,
@@ -387,7 +450,7 @@ int accblas_comm_acc_gemv(accblas_comm *comm, accblas_dtype ar,
     if (status != ACCBLAS_OK || res_full == nullptr) {
         return status;
     }
-    if (comm->world_size == 1) {
+    if (comm->world_size == 1 && !comm->always_collective) {
         if (res_full == res_local) {
             return ACCBLAS_OK;
         }

@@ -13,6 +13,7 @@
 namespace {
 std::atomic<int> trsv_split_option{0};
 std::atomic<int> trsv_wide_option{0};
+std::atomic<int> trsv_relay_option{1};
 std::atomic<int> gemv_skew_option_store{1};
 }
 
@@ -20,6 +21,7 @@ int accblas::gemv_skew_option_value() { return gemv_skew_option_store.load(); }
 
 bool accblas::trsv_split_enabled() { return trsv_split_option.load() != 0; }
 bool accblas::trsv_wide_enabled() { return trsv_wide_option.load() != 0; }
+int accblas::trsv_relay_option_value() { return trsv_relay_option.load(); }
 
 extern "C" int accblas_set_option(const char *name, int value)
 {
@@ -29,6 +31,14 @@ extern "C" int accblas_set_option(const char *name, int value)
     }
     if (name != nullptr && std::string(name) == "trsv_wide") {
         trsv_wide_option.store(value);
+        return ACCBLAS_OK;
+    }
+    if (name != nullptr && std::string(name) == "trsv_relay") {
+        if (value < 0 || value > 2) {
+            return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
+                                      "trsv_relay takes 0, 1 or 2");
+        }
+        trsv_relay_option.store(value);
         return ACCBLAS_OK;
     }
     if (name != nullptr && std::string(name) == "gemv_skew") {

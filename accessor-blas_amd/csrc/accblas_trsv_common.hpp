@@ -32,6 +32,8 @@ int trsv_num_cus();
 /** Options "trsv_split" / "trsv_wide" (accblas_set_option). */
 bool trsv_split_enabled();
 bool trsv_wide_enabled();
+/** Option "trsv_relay": 0 never, 1 by the measured rule (default), 2 always. */
+int trsv_relay_option_value();
 
 
 /** Picks the role-split kernel for large aligned systems, `kernel::trsv`
@@ -83,7 +85,8 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
         return status;
     }
     return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x, helper,
-                                               session, as_stream(stream)),
+                                               session, as_stream(stream),
+                                               trsv_relay_option_value()),
                      "trsv launch");
 }
 

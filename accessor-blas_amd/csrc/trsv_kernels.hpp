@@ -340,6 +340,190 @@ struct granule_io {
 };
 
 
+
+/** K-loop of one 16 x 16 output tile on the matrix cores:
+ *  sum_{k in [k_begin, k_end)} A[.][k] B[k][.], k_end - k_begin a multiple of
+ *  16. `a_of(k)` / `b_of(k)` return this lane's operand for column / row k of
+ *  the step (lane l supplies k = k0 + (l >> 4), see mma_16x16x4); the eight
+ *  operand fetches of a pass are issued before its four dependent MFMAs. */
+template <typename T, typename AFetch, typename BFetch>
+__device__ __forceinline__ typename mma_16x16x4<T>::acc_type mma_tile_product(
+    int k_begin, int k_end, int frag_k, AFetch a_of, BFetch b_of)
+{
+    using mma = mma_16x16x4<T>;
+    typename mma::acc_type acc{};
+    for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+        T a[4];
+        T b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[q] = a_of(k0 + q * 4 + frag_k);
+            b[q] = b_of(k0 + q * 4 + frag_k);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc = mma::step(a[q], b[q], acc);
+        }
+    }
+    return acc;
+}
+
+
+/**
+ * In-place inverse of a 64 x 64 lower-triangular tile in LDS by a team of (at
+ * least) four waves; every thread of the team must call it (it contains team
+ * barriers = __syncthreads(): all teams of the workgroup call it together).
+ *
+ * In: T row-major, `tile[r * ld + c]`, zeros above the diagonal, ld = 65.
+ * Out: inv(T) column-major, `tile[c * ld + r]`, zeros above the diagonal.
+ * For T = [T00 0; C T11]: inv(T) = [X00 0; -X11 C X00, X11]. The serial part
+ * is only 16 rows long: the four 16-lane groups of team wave 0 invert the four
+ * diagonal 16 x 16 blocks in one instruction stream (lanes own columns in
+ * registers, X[i][j] = (delta_ij - sum_{k<i} T[i][k] X[k][j]) / T[i][i]). The
+ * two merge levels (16 -> 32 -> 64) are small dense products on the matrix
+ * cores; the intermediate C X00 passes through `scratch_a` / `scratch_b` (512
+ * words each) to get from the MFMA result layout into the operand layout.
+ * Every finished block of the inverse overwrites zeros or its own source, and
+ * the off-diagonal source blocks are cleared once they have been used.
+ * `team_wave` = index of the calling wave in its team (waves >= 4 only take
+ * part in the barriers and the final clearing), `team_thread` / `team_size` =
+ * index of the thread in the team and the team's thread count.
+ */
+template <bool UnitDiag, typename ar_type>
+__device__ __forceinline__ void invert_tile64(ar_type *tile, ar_type *scratch_a,
+                                              ar_type *scratch_b, int team_wave,
+                                              int lane, int team_thread,
+                                              int team_size)
+{
+    constexpr int ld = trsv_tile + 1;
+    const int wave = team_wave;
+    ar_type *const partial_a = scratch_a;
+    ar_type *const partial_b = scratch_b;
+    {
+        using mma = mma_16x16x4<ar_type>;
+        constexpr int Q = 16;  // base block / MFMA tile edge
+        const int frag_ij = lane & 15;
+        const int frag_k = lane >> 4;
+        if (wave == 0) {
+            const int off = frag_k * Q;  // this 16-lane group's block
+            ar_type column[Q];
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                // a dependent fp64 FMA chain costs ~40 cycles per link on
+                // gfx950: four interleaved partial sums per row
+                ar_type sums[4] = {};
+#pragma unroll
+                for (int k = 0; k < i; ++k) {
+                    sums[k & 3] += tile[(off + i) * ld + off + k] * column[k];
+                }
+                ar_type value = ((frag_ij == i) ? ar_type{1} : ar_type{0}) -
+                                ((sums[0] + sums[1]) + (sums[2] + sums[3]));
+                if (!UnitDiag) {
+                    value = value / tile[(off + i) * ld + off + i];
+                }
+                column[i] = value;
+            }
+            // all reads of the four diagonal blocks are done (same wave,
+            // program order): overwrite them with their inverses
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                tile[(off + frag_ij) * ld + off + i] = column[i];
+            }
+        }
+        __syncthreads();
+        // level 1, waves 0 and 1: the 32 x 32 diagonal block at o = 32 * wave.
+        // P = C X00 (16 x 16 x 16), through this wave's 256 words of
+        // partial_a, then X10 = -X11 P.
+        if (wave < 2) {
+            const int o = 2 * Q * wave;
+            ar_type *scratch = partial_a + wave * Q * Q;
+            typename mma::acc_type p{};
+#pragma unroll
+            for (int k0 = 0; k0 < Q; k0 += 4) {
+                const int k = k0 + frag_k;
+                p = mma::step(tile[(o + Q + frag_ij) * ld + o + k],  // C[i][k]
+                              tile[(o + frag_ij) * ld + o + k],      // X00[k][j]
+                              p);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                scratch[mma::row(lane, reg) * Q + frag_ij] = p[reg];
+            }
+            typename mma::acc_type x10{};
+#pragma unroll
+            for (int k0 = 0; k0 < Q; k0 += 4) {
+                const int k = k0 + frag_k;
+                x10 = mma::step(
+                    tile[(o + Q + k) * ld + o + Q + frag_ij],  // X11[i][k]
+                    scratch[k * Q + frag_ij],                  // P[k][j]
+                    x10);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                // X10[r][c] of the inverse, column-major
+                tile[(o + frag_ij) * ld + o + Q + mma::row(lane, reg)] =
+                    -x10[reg];
+            }
+            // C (rows o+16.., columns o..o+15, row-major) is used up; in the
+            // inverse's layout that region is above the diagonal: zero
+#pragma unroll
+            for (int e = lane; e < Q * Q; e += wave_size) {
+                tile[(o + Q + e / Q) * ld + o + e % Q] = ar_type{};
+            }
+        }
+        __syncthreads();
+        // level 2: X10 (32 x 32) = -X11 (C X00) with the two 32 x 32 inverses.
+        // Waves 0..3 own one 16 x 16 tile each; P = C X00 is handed over
+        // through partial_a (waves 0, 1) and partial_b (waves 2, 3).
+        constexpr int H = 2 * Q;
+        const int ti = (wave >> 1) & 1;
+        const int tj = wave & 1;
+        ar_type *const scratch2 =
+            (wave < 2 ? partial_a : partial_b) + (wave & 1) * Q * Q;
+        if (wave < 4) {
+            typename mma::acc_type p{};
+            // X00 is lower triangular: rows above column tile tj are zero
+            for (int k0 = tj * Q; k0 < H; k0 += 4) {
+                const int k = k0 + frag_k;
+                p = mma::step(tile[(H + ti * Q + frag_ij) * ld + k],  // C[i][k]
+                              tile[(tj * Q + frag_ij) * ld + k],      // X00[k][j]
+                              p);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                scratch2[mma::row(lane, reg) * Q + frag_ij] = p[reg];
+            }
+        }
+        __syncthreads();
+        if (wave < 4) {
+            typename mma::acc_type x10{};
+            // X11 is lower triangular: columns beyond row tile ti are zero
+            for (int k0 = 0; k0 < (ti + 1) * Q; k0 += 4) {
+                const int k = k0 + frag_k;
+                // P tile (k / 16, tj) was written by wave 2 * (k / 16) + tj
+                const ar_type *src =
+                    ((k / Q) == 0 ? partial_a : partial_b) + tj * Q * Q;
+                x10 = mma::step(
+                    tile[(H + k) * ld + H + ti * Q + frag_ij],  // X11[i][k]
+                    src[(k % Q) * Q + frag_ij],                 // P[k][j]
+                    x10);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                tile[(tj * Q + frag_ij) * ld + H + ti * Q +
+                     mma::row(lane, reg)] = -x10[reg];
+            }
+        }
+        __syncthreads();
+        // C (rows >= 32, columns < 32, row-major) is used up: the upper-right
+        // block of the inverse is zero
+        for (int e = team_thread; e < H * H; e += team_size) {
+            tile[(H + e / H) * ld + e % H] = ar_type{};
+        }
+    }
+}
+
+
 }  // namespace detail
 
 
@@ -497,142 +681,12 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
         ACCBLAS_TRSV_STAMP(block, 10);  // tile and panel staged
     }
 
-    // ---- invert the tile: 16 x 16 substitutions, then two merge levels -----
-    // For T = [T00 0; C T11]: inv(T) = [X00 0; -X11 C X00, X11]. The serial
-    // part is only 16 rows long: the four 16-lane groups of wave 0 invert the
-    // four diagonal 16 x 16 blocks in one instruction stream (lanes own
-    // columns in registers, X[i][j] = (delta_ij - sum_{k<i} T[i][k] X[k][j]) /
-    // T[i][i]). The two merge levels (16 -> 32 -> 64) are small dense products
-    // on the matrix cores; the intermediate C X00 passes through LDS to get
-    // from the MFMA result layout into the operand layout. T is row-major
-    // (tile[r * ld + c]), the inverse column-major (tile[c * ld + r]): every
-    // finished block of the inverse overwrites zeros or its own source, and
-    // the off-diagonal source blocks are cleared once they have been used.
-    {
-        using mma = detail::mma_16x16x4<ar_type>;
-        constexpr int Q = 16;  // base block / MFMA tile edge
-        static_assert(Waves >= 8,
-                      "the merge levels use four waves and 2 x 512 words of "
-                      "the partial-sum buffers");
-        const int frag_ij = lane & 15;
-        const int frag_k = lane >> 4;
-        if (wave == 0) {
-            const int off = frag_k * Q;  // this 16-lane group's block
-            ar_type column[Q];
-#pragma unroll
-            for (int i = 0; i < Q; ++i) {
-                // a dependent fp64 FMA chain costs ~40 cycles per link on
-                // gfx950: four interleaved partial sums per row
-                ar_type sums[4] = {};
-#pragma unroll
-                for (int k = 0; k < i; ++k) {
-                    sums[k & 3] += tile[(off + i) * ld + off + k] * column[k];
-                }
-                ar_type value = ((frag_ij == i) ? ar_type{1} : ar_type{0}) -
-                                ((sums[0] + sums[1]) + (sums[2] + sums[3]));
-                if (!UnitDiag) {
-                    value = value / tile[(off + i) * ld + off + i];
-                }
-                column[i] = value;
-            }
-            // all reads of the four diagonal blocks are done (same wave,
-            // program order): overwrite them with their inverses
-#pragma unroll
-            for (int i = 0; i < Q; ++i) {
-                tile[(off + frag_ij) * ld + off + i] = column[i];
-            }
-        }
-        __syncthreads();
-        // level 1, waves 0 and 1: the 32 x 32 diagonal block at o = 32 * wave.
-        // P = C X00 (16 x 16 x 16), through this wave's 256 words of
-        // partial_a, then X10 = -X11 P.
-        if (wave < 2) {
-            const int o = 2 * Q * wave;
-            ar_type *scratch = partial_a + wave * Q * Q;
-            typename mma::acc_type p{};
-#pragma unroll
-            for (int k0 = 0; k0 < Q; k0 += 4) {
-                const int k = k0 + frag_k;
-                p = mma::step(tile[(o + Q + frag_ij) * ld + o + k],  // C[i][k]
-                              tile[(o + frag_ij) * ld + o + k],      // X00[k][j]
-                              p);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                scratch[mma::row(lane, reg) * Q + frag_ij] = p[reg];
-            }
-            typename mma::acc_type x10{};
-#pragma unroll
-            for (int k0 = 0; k0 < Q; k0 += 4) {
-                const int k = k0 + frag_k;
-                x10 = mma::step(
-                    tile[(o + Q + k) * ld + o + Q + frag_ij],  // X11[i][k]
-                    scratch[k * Q + frag_ij],                  // P[k][j]
-                    x10);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                // X10[r][c] of the inverse, column-major
-                tile[(o + frag_ij) * ld + o + Q + mma::row(lane, reg)] =
-                    -x10[reg];
-            }
-            // C (rows o+16.., columns o..o+15, row-major) is used up; in the
-            // inverse's layout that region is above the diagonal: zero
-#pragma unroll
-            for (int e = lane; e < Q * Q; e += wave_size) {
-                tile[(o + Q + e / Q) * ld + o + e % Q] = ar_type{};
-            }
-        }
-        __syncthreads();
-        // level 2: X10 (32 x 32) = -X11 (C X00) with the two 32 x 32 inverses.
-        // Waves 0..3 own one 16 x 16 tile each; P = C X00 is handed over
-        // through partial_a (waves 0, 1) and partial_b (waves 2, 3).
-        constexpr int H = 2 * Q;
-        const int ti = (wave >> 1) & 1;
-        const int tj = wave & 1;
-        ar_type *const scratch2 =
-            (wave < 2 ? partial_a : partial_b) + (wave & 1) * Q * Q;
-        if (wave < 4) {
-            typename mma::acc_type p{};
-            // X00 is lower triangular: rows above column tile tj are zero
-            for (int k0 = tj * Q; k0 < H; k0 += 4) {
-                const int k = k0 + frag_k;
-                p = mma::step(tile[(H + ti * Q + frag_ij) * ld + k],  // C[i][k]
-                              tile[(tj * Q + frag_ij) * ld + k],      // X00[k][j]
-                              p);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                scratch2[mma::row(lane, reg) * Q + frag_ij] = p[reg];
-            }
-        }
-        __syncthreads();
-        if (wave < 4) {
-            typename mma::acc_type x10{};
-            // X11 is lower triangular: columns beyond row tile ti are zero
-            for (int k0 = 0; k0 < (ti + 1) * Q; k0 += 4) {
-                const int k = k0 + frag_k;
-                // P tile (k / 16, tj) was written by wave 2 * (k / 16) + tj
-                const ar_type *src =
-                    ((k / Q) == 0 ? partial_a : partial_b) + tj * Q * Q;
-                x10 = mma::step(
-                    tile[(H + k) * ld + H + ti * Q + frag_ij],  // X11[i][k]
-                    src[(k % Q) * Q + frag_ij],                 // P[k][j]
-                    x10);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                tile[(tj * Q + frag_ij) * ld + H + ti * Q +
-                     mma::row(lane, reg)] = -x10[reg];
-            }
-        }
-        __syncthreads();
-        // C (rows >= 32, columns < 32, row-major) is used up: the upper-right
-        // block of the inverse is zero
-        for (int e = threadIdx.x; e < H * H; e += blockDim.x) {
-            tile[(H + e / H) * ld + e % H] = ar_type{};
-        }
-    }
+    // ---- invert the tile (recursively; see detail::invert_tile64) -----------
+    static_assert(Waves >= 8, "the partial-sum buffers double as the 4 x 256 "
+                              "words of scratch of the inversion");
+    detail::invert_tile64<UnitDiag>(tile, partial_a, partial_b, wave, lane,
+                                    static_cast<int>(threadIdx.x),
+                                    static_cast<int>(blockDim.x));
     if (wave == 0) {
         ACCBLAS_TRSV_STAMP(block, 1);  // inverse ready
     }
@@ -1059,15 +1113,11 @@ constexpr unsigned trsv_single_block_pad()
 
 
 /** When the far sweep's x goes through the loader wave and LDS (measured,
- *  profiles/r01_trsv_relay_ab.txt). ACCBLAS_TRSV_RELAY_MODE: 0 never, 1 by
- *  size, 2 always (A/B builds). */
-#ifndef ACCBLAS_TRSV_RELAY_MODE
-#define ACCBLAS_TRSV_RELAY_MODE 1
-#endif
+ *  profiles/r01_trsv_relay_ab.txt). `relay_mode` of `launch_trsv` (option
+ *  "trsv_relay" of accblas_set_option): 0 never, 1 by this rule, 2 always. */
 #ifndef ACCBLAS_TRSV_RELAY_MIN_N
 #define ACCBLAS_TRSV_RELAY_MIN_N 17000
 #endif
-constexpr int trsv_relay_mode = ACCBLAS_TRSV_RELAY_MODE;
 constexpr index_type trsv_relay_min_n = ACCBLAS_TRSV_RELAY_MIN_N;
 
 /** Workgroups (= tickets) a solve of n unknowns launches. */
@@ -1080,7 +1130,8 @@ inline unsigned trsv_num_blocks(index_type n)
 template <typename ArType, typename MtxView, typename XView>
 hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
                        const XView &x, std::uint32_t *helper,
-                       const trsv_session &session, hipStream_t stream)
+                       const trsv_session &session, hipStream_t stream,
+                       int relay_mode = 1)
 {
     using mtx_traits = view_traits<MtxView>;
     using st_type =
@@ -1108,8 +1159,7 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     constexpr bool float_arithmetic = std::is_same<ArType, float>::value;
     const bool by_rule = half_storage || float_arithmetic ||
                          (double_storage && n >= trsv_relay_min_n);
-    const bool relay =
-        trsv_relay_mode == 2 || (trsv_relay_mode == 1 && by_rule);
+    const bool relay = relay_mode == 2 || (relay_mode == 1 && by_rule);
     const dim3 block((waves + (relay ? 1 : 0)) * wave_size, 1, 1);
     const unsigned pad = relay ? trsv_single_block_pad<ArType, waves, true>()
                                : trsv_single_block_pad<ArType, waves, false>();

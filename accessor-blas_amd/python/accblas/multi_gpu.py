@@ -21,41 +21,57 @@ tests, on the CPU oracle.
 """
 
 
-def shard_bounds(total, world_size, rank):
-    """Contiguous block [lo, hi) of `total` items owned by `rank`; blocks differ
-    by at most one item and cover [0, total) exactly."""
+def shard_bounds(total, world_size, rank, align=1):
+    """Contiguous block [lo, hi) of `total` items owned by `rank`; the blocks
+    cover [0, total) exactly and, with align = 1, differ by at most one item.
+    With align > 1 every interior block edge is rounded down to a multiple of
+    `align` items (the same rule as `accblas_shard_bounds` of
+    include/accblas_comm.h): dot chunks use align = 16 bytes / sizeof(storage)
+    so that every chunk keeps the 16-byte vector loads (an unaligned start
+    silently drops to the scalar path), GEMV row blocks use align = 64 rows so
+    that a row's summation order is the same alone as inside the full
+    product."""
     if world_size < 1 or not 0 <= rank < world_size:
         raise ValueError("bad world_size / rank")
+    if align < 1:
+        raise ValueError("align must be >= 1")
     base, extra = divmod(total, world_size)
-    lo = rank * base + min(rank, extra)
-    hi = lo + base + (1 if rank < extra else 0)
-    return lo, hi
+
+    def edge(r):
+        if r >= world_size:
+            return total
+        e = r * base + min(r, extra)
+        return e - e % align
+
+    return edge(rank), edge(rank + 1)
 
 
-def sharded_dot(local_dot, n, dist=None, group=None):
+def sharded_dot(local_dot, n, dist=None, group=None, align=1):
     """`local_dot(lo, hi)` must return a 1-element tensor of the arithmetic type
     holding sum_{lo <= i < hi} x_i * y_i on the communicator's device. Returns
-    that tensor after the all-reduce (every rank holds the full dot)."""
+    that tensor after the all-reduce (every rank holds the full dot). `align`:
+    see `shard_bounds` (16 bytes / sizeof(storage) keeps the vector path)."""
     world = dist.get_world_size(group) if dist is not None else 1
     rank = dist.get_rank(group) if dist is not None else 0
-    lo, hi = shard_bounds(n, world, rank)
+    lo, hi = shard_bounds(n, world, rank, align)
     partial = local_dot(lo, hi)
     if world > 1:
         dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
     return partial
 
 
-def sharded_gemv(local_gemv, rows, dist=None, group=None, gather=False, res_full=None):
+def sharded_gemv(local_gemv, rows, dist=None, group=None, gather=False, res_full=None,
+                 align=1):
     """`local_gemv(lo, hi)` computes rows [lo, hi) in place in this rank's slice
     and returns that slice (a tensor of hi - lo elements). With gather=True the
-    slices are all-gathered into `res_full` (rows elements, pre-allocated); rows
-    must then divide evenly."""
+    slices are all-gathered into `res_full` (rows elements, pre-allocated); the
+    row blocks must then all have the same size."""
     world = dist.get_world_size(group) if dist is not None else 1
     rank = dist.get_rank(group) if dist is not None else 0
-    lo, hi = shard_bounds(rows, world, rank)
+    lo, hi = shard_bounds(rows, world, rank, align)
     piece = local_gemv(lo, hi)
     if gather and world > 1:
-        if rows % world != 0:
+        if rows % (world * align) != 0:
             raise ValueError("gather needs rows divisible by the number of ranks")
         dist.all_gather_into_tensor(res_full, piece, group=group)
         return res_full

@@ -5,16 +5,22 @@ Workload (BASELINE.json north_star target, config "GEMV 32768x32768,
 storage=fp32 arithmetic=fp64"): res = alpha*A*x + beta*res with alpha=beta=1
 (`/root/reference/cuda/gemv_benchmark.cu:25-28`), A row-major n x n fp32 in HBM,
 arithmetic in fp64, `acc_gemv<double, float>` (`cuda/gemv_kernels.cuh:168-193`).
-A "step" is one such GEMV. Inputs are resident in HBM before the timed region.
+A "step" is one such GEMV of the WHOLE n x n problem. Inputs are resident in HBM
+before the timed region.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1: GEMV shards by row blocks with NO data-path collective (SURVEY.md §8e
-E1): rank g owns rows [g*n, (g+1)*n) of a (N*n) x n matrix, a replica of x and
-its slice of res ("weak" scaling: fixed work per GPU). One process per GPU,
-torch.distributed (RCCL) only for the barrier and the max-over-ranks time.
+N > 1 ("scaling": "strong"): the SAME n x n problem is split
+into row blocks, rank g owns rows shard_bounds(n, N, g, align=64) of A (n/N
+rows), a replica of x and its slice of res; the timed step is every rank's
+row-block GEMV, which needs NO data-path collective. One process per GPU,
+torch.distributed (RCCL) for the barrier, the max-over-ranks time and the
+measurements reported beside the headline under "multi_gpu": the kernel-only
+time, the end-to-end step without and WITH the all-gather of the result slices
+(`multi_gpu.sharded_gemv(gather=True)`), per-GPU GB/s, and the weak-scaling
+number (every rank a full n x n block) as a second field.
 
 Prints ONE JSON line on rank 0 (see the keys below). Conventions: flops = 2*n^2
 per GEMV, algorithmic bytes = s*(n^2 + 3n), s = sizeof(storage) (SURVEY.md §8d
@@ -102,6 +108,12 @@ class HostStagedCollectives:
         self._dist.all_reduce(host, op=op, group=group)
         tensor.copy_(host)
 
+    def all_gather_into_tensor(self, output, tensor, group=None):
+        host_in = tensor.cpu()
+        host_out = output.cpu()
+        self._dist.all_gather_into_tensor(host_out, host_in, group=group)
+        output.copy_(host_out)
+
     def destroy_process_group(self):
         self._dist.destroy_process_group()
 
@@ -158,48 +170,74 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank):
     # ranks, one all-reduce of a single fp32 element
     from accblas import multi_gpu
     n_total = 1 << 28
-    lo, hi = multi_gpu.shard_bounds(n_total, world, rank)
+    align = 16 // 2  # chunk starts stay 16-byte aligned for the vector loads
+    lo, hi = multi_gpu.shard_bounds(n_total, world, rank, align)
     count = hi - lo
+    # A chunk of 2^25 fp16 pairs (the 8-GPU share) is 134 MB: it stays in the
+    # 256 MiB Infinity Cache between repetitions. `copies` buffers, swept in
+    # turn, keep more than 512 MiB between two uses of the same line, so the
+    # rotating time is the HBM one; both are reported.
+    copies = max(1, -(-(640 << 20) // (4 * count)))
     x64 = uniform(count, torch.float64, seed=100 + rank)
     y64 = uniform(count, torch.float64, seed=200 + rank)
-    xh = torch.empty(count, dtype=torch.float16, device=dev)
-    yh = torch.empty(count, dtype=torch.float16, device=dev)
+    xh = torch.empty(copies * count, dtype=torch.float16, device=dev)
+    yh = torch.empty(copies * count, dtype=torch.float16, device=dev)
     accblas.convert(F16, xh, F64, x64, count, stream)
     accblas.convert(F16, yh, F64, y64, count, stream)
+    for c in range(1, copies):
+        xh[c * count:(c + 1) * count].copy_(xh[:count])
+        yh[c * count:(c + 1) * count].copy_(yh[:count])
     handle = accblas.Handle()
     partial = torch.zeros(1, dtype=torch.float32, device=dev)
     ref = torch.zeros(1, dtype=torch.float64, device=dev)
     accblas.dot(handle, F64, count, x64, 1, y64, 1, ref, stream)  # fp64 reference
+    turn = [0]
 
-    def local_dot(_lo, _hi):
-        accblas.acc_dot(handle, F32, F16, F32, count, xh, 1, yh, 1, partial, stream)
+    def local_dot(_lo, _hi, rotate=True):
+        c = turn[0] % copies if rotate else 0
+        turn[0] += 1
+        accblas.acc_dot(handle, F32, F16, F32, count, xh[c * count:], 1, yh[c * count:], 1,
+                        partial, stream)
         return partial
 
-    t_kernel = event_time_us(accblas, torch, lambda: local_dot(lo, hi), stream)
-    reps = 20
-    multi_gpu.sharded_dot(local_dot, n_total, dist=dist)  # warm-up incl. RCCL
+    t_resident = event_time_us(accblas, torch, lambda: local_dot(lo, hi, rotate=False), stream)
+    reps = 4 * copies
+    torch.cuda.synchronize()
+    a, b = accblas.Event(), accblas.Event()
+    a.record(stream)
+    for _ in range(reps):
+        local_dot(lo, hi)
+    b.record(stream)
+    b.synchronize()
+    t_kernel = a.elapsed_ms(b) * 1e3 / reps
+    multi_gpu.sharded_dot(local_dot, n_total, dist=dist, align=align)  # warm-up incl. RCCL
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        total = multi_gpu.sharded_dot(local_dot, n_total, dist=dist)
+        total = multi_gpu.sharded_dot(local_dot, n_total, dist=dist, align=align)
     torch.cuda.synchronize()
     t_e2e = (time.perf_counter() - t0) / reps * 1e6
     got = float(total.item())
     if dist is not None:
         dist.all_reduce(ref, op=dist.ReduceOp.SUM)
-        t = torch.tensor([t_kernel, t_e2e], dtype=torch.float64, device=dev)
+        t = torch.tensor([t_kernel, t_e2e, t_resident], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_kernel, t_e2e = float(t[0]), float(t[1])
+        t_kernel, t_e2e, t_resident = float(t[0]), float(t[1]), float(t[2])
     want = float(ref.item())
     out["dot_2p28_fp16_fp32"] = {
         "elements_per_gpu": count, "kernel_us": t_kernel,
         "kernel_GBs_per_gpu": 4.0 * count / t_kernel / 1e3,
+        "kernel_frac_of_8TBs": 4.0 * count / t_kernel / 1e3 / HBM_PEAK_GBS,
+        "kernel_us_same_buffers": t_resident,
+        "kernel_GBs_per_gpu_same_buffers": 4.0 * count / t_resident / 1e3,
+        "rotating_buffer_sets": copies,
         "end_to_end_us_incl_allreduce": t_e2e,
         "aggregate_GBs_end_to_end": 4.0 * n_total / t_e2e / 1e3,
         "collective": "all_reduce(sum) of 1 fp32 element" if world > 1 else "none",
+        "world_size_seen_by_backend": dist.get_world_size() if dist is not None else 1,
         "rel_err_vs_fp64": abs(got - want) / abs(want)}
     handle.close()
     del x64, y64, xh, yh
@@ -240,6 +278,49 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank):
     return out
 
 
+def timed_loop(step, steps, warmup, barrier, record=None):
+    """`warmup` untimed steps, then exactly `steps` steps bracketed by
+    barrier() on both sides; `record(which)` (0 = start, 1 = stop) marks the
+    stream inside the bracket. Returns the wall-clock seconds of the bracket."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    if record is not None:
+        record(0)
+    for _ in range(steps):
+        step()
+    if record is not None:
+        record(1)
+    barrier()
+    return time.perf_counter() - t0
+
+
+GEMV_ROW_ALIGN = 64  # row blocks start at multiples of 64 rows (same bits as alone)
+
+
+def strong_gemv(local_gemv, rows, dist, steps, warmup, barrier, record=None,
+                gather_into=None):
+    """The N > 1 step of this benchmark: the fixed
+    rows x cols problem split into contiguous row blocks, rank g computing
+    rows shard_bounds(rows, N, g, align=64) with `local_gemv(lo, hi)` (which
+    returns its slice of the result). Without `gather_into` there is no
+    collective on the data path; with it every step ends in ONE all-gather of
+    the slices into that tensor. Returns (lo, hi, seconds of the timed loop).
+    Used by main() on the HIP kernels and by tests/test_distributed.py on the
+    oracle (gloo)."""
+    from accblas import multi_gpu
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    lo, hi = multi_gpu.shard_bounds(rows, world, rank, GEMV_ROW_ALIGN)
+
+    def step():
+        multi_gpu.sharded_gemv(local_gemv, rows, dist=dist, gather=gather_into is not None,
+                               res_full=gather_into, align=GEMV_ROW_ALIGN)
+
+    return lo, hi, timed_loop(step, steps, warmup, barrier, record)
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -265,16 +346,19 @@ def main():
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     dist = None
+    backend = "none"
     if world > 1:
         import torch.distributed as torch_dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
             torch_dist.init_process_group(backend="gloo", rank=rank, world_size=world)
             dist = HostStagedCollectives(torch_dist)
+            backend = "gloo (host-staged rehearsal, ranks share one GPU)"
         else:
             torch_dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                           device_id=dev)
             dist = torch_dist
+            backend = "nccl (RCCL)"
 
     codes = {"f16": accblas.F16, "f32": accblas.F32, "f64": accblas.F64}
     st, ar = codes[args.st], codes[args.ar]
@@ -283,13 +367,14 @@ def main():
     rows, cols, lda = n, n, n
 
     # ---- synthetic inputs, generated on the device (U(-1,1) fp64 master, then
-    # the reference's static_cast to the storage type, gemv_memory.cuh:92-97)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(42 + rank)
+    # the reference's static_cast to the storage type, gemv_memory.cuh:92-97).
+    # Every rank draws the SAME n x n problem (same seeds) and keeps its rows.
     stream = torch.cuda.current_stream()
 
-    def uniform(count, generator):
-        return torch.rand(count, dtype=torch.float64, device=dev, generator=generator) \
+    def uniform(count, seed):
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        return torch.rand(count, dtype=torch.float64, device=dev, generator=g) \
             .mul_(2.0).sub_(1.0)
 
     def to_storage(master):
@@ -297,11 +382,9 @@ def main():
         accblas.convert(st, out, accblas.F64, master, master.numel(), stream)
         return out
 
-    gen_x = torch.Generator(device=dev)
-    gen_x.manual_seed(7)  # x is replicated: same on every rank
-    x64 = uniform(cols, gen_x)
-    res64 = uniform(rows, gen)
-    A64 = uniform(rows * lda, gen)
+    x64 = uniform(cols, 7)
+    res64 = uniform(rows, 43)
+    A64 = uniform(rows * lda, 42)
     A_st, x_st, res0_st = to_storage(A64), to_storage(x64), to_storage(res64)
     torch.cuda.synchronize()
 
@@ -316,32 +399,74 @@ def main():
     del A64
     torch.cuda.empty_cache()
 
-    def step():
-        accblas.acc_gemv(ar, st, rows, cols, 1.0, A_st, lda, x_st, 1, 1.0, res_st, 1, stream)
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ev_start, ev_stop = accblas.Event(), accblas.Event()
-    barrier()
-    t0 = time.perf_counter()
-    ev_start.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev_stop.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev_start.elapsed_ms(ev_stop) / args.steps
+    def local_gemv(lo, hi):
+        """rows [lo, hi) of the problem, in place in this rank's slice of res."""
+        accblas.acc_gemv(ar, st, hi - lo, cols, 1.0, A_st[lo * lda:], lda, x_st, 1, 1.0,
+                         res_st[lo:], 1, stream)
+        return res_st[lo:hi]
 
-    if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    events = [accblas.Event(), accblas.Event()]
+
+    def record(which):
+        events[which].record(stream)
+
+    def reduce_max(values):
+        if dist is None:
+            return values
+        t = torch.tensor(values, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+        return [float(v) for v in t]
+
+    # ---- the timed region: K steps of the whole problem, row blocks over ranks
+    lo, hi, elapsed = strong_gemv(local_gemv, rows, dist, args.steps, args.warmup, barrier,
+                                  record)
+    local_rows = hi - lo
+    kernel_ms = events[0].elapsed_ms(events[1]) / args.steps
+    elapsed, kernel_ms = reduce_max([elapsed, kernel_ms])
+
+    multi = None
+    if world > 1:
+        # the row block result equals the rows of the single-GPU product bit for bit
+        res_check = res0_st.clone()
+        accblas.acc_gemv(ar, st, local_rows, cols, 1.0, A_st[lo * lda:], lda, x_st, 1, 1.0,
+                         res_check[lo:], 1, stream)
+        torch.cuda.synchronize()
+        same_bits = bool(torch.equal(res_check[lo:hi], first_result[lo:hi]))
+        # end-to-end step WITH the all-gather of the result slices
+        res_full = torch.empty(rows, dtype=accblas.torch_dtype(st), device=dev)
+        gather_ok = rows % (world * GEMV_ROW_ALIGN) == 0
+        t_gather = None
+        if gather_ok:
+            _, _, t_gather = strong_gemv(local_gemv, rows, dist, args.steps, args.warmup,
+                                         barrier, gather_into=res_full)
+        # weak scaling as a second field: every rank a full rows x cols block
+        def weak_step():
+            accblas.acc_gemv(ar, st, rows, cols, 1.0, A_st, lda, x_st, 1, 1.0, res_st, 1,
+                             stream)
+        t_weak = timed_loop(weak_step, args.steps, args.warmup, barrier)
+        t_gather, t_weak = reduce_max([t_gather or 0.0, t_weak])
+        local_bytes = st_bytes * (local_rows * cols + 2.0 * local_rows + cols)
+        multi = {
+            "mode": "strong: the rows x cols problem split into row blocks",
+            "backend": backend,
+            "world_size_seen_by_backend": dist.get_world_size(),
+            "rows_per_gpu": local_rows,
+            "kernel_us": kernel_ms * 1e3,
+            "per_gpu_GBs": local_bytes / (kernel_ms * 1e-3) / 1e9,
+            "per_gpu_frac_of_8TBs": local_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "end_to_end_us_no_gather": elapsed / args.steps * 1e6,
+            "end_to_end_us_with_allgather":
+                t_gather / args.steps * 1e6 if gather_ok else None,
+            "row_block_equals_single_gpu_rows_bitwise": same_bits,
+            "weak": {"rows_per_gpu": rows, "ms_per_step": t_weak / args.steps * 1e3,
+                     "value_GFLOPs": 2.0 * rows * cols * world * args.steps / t_weak / 1e9},
+        }
 
     # CPU-baseline sample: half of the rows (2 GiB of fp32 on the host), swept
     # `cpu_reps` times by all threads: about 10 core-seconds of CPU work
@@ -359,8 +484,8 @@ def main():
             dist.destroy_process_group()
         return
 
-    flops_per_step = 2.0 * rows * cols * world
-    bytes_per_launch = st_bytes * (rows * cols + 2.0 * rows + cols)
+    flops_per_step = 2.0 * rows * cols
+    bytes_per_launch = st_bytes * (local_rows * cols + 2.0 * local_rows + cols)
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     out = {
         "metric": "GEMV GFLOP/s + achieved HBM GB/s (% of peak) per (st_t,ar_t); "
@@ -372,18 +497,20 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": args.ar,
         "data": "synthetic: U(-1,1) fp64 master drawn on the device (torch Philox), "
                 "static_cast to the storage type; alpha=beta=1",
         "config": {
-            "workload": f"GEMV {rows}x{cols} per GPU, storage={args.st} "
-                        f"arithmetic={args.ar}, acc_gemv through "
-                        "range<reduced_row_major<2,ar,st>> (BASELINE configs[2], "
-                        "the north_star target)",
-            "rows_per_gpu": rows, "cols": cols, "lda": lda,
-            "sharding": "row blocks, x replicated, no collective" if world > 1 else "none",
+            "workload": f"GEMV {rows}x{cols}, storage={args.st} arithmetic={args.ar}, "
+                        "acc_gemv through range<reduced_row_major<2,ar,st>> (BASELINE "
+                        "configs[2], the north_star target)"
+                        + (f", split into {world} row blocks of {local_rows} rows"
+                           if world > 1 else ""),
+            "rows": rows, "cols": cols, "lda": lda, "rows_per_gpu": local_rows,
+            "sharding": "row blocks, x replicated, no collective in the timed step"
+                        if world > 1 else "none",
             "flops_per_gemv": "2*rows*cols",
             "bytes_per_gemv": "s*(rows*cols + 2*rows + cols)",
         },
@@ -397,13 +524,20 @@ def main():
             "traffic": None,
             "kernel_us": kernel_ms * 1e3,
             "algorithmic_bytes_per_launch": bytes_per_launch,
-            "achieved_gflops_per_gpu": 2.0 * rows * cols / (kernel_ms * 1e-3) / 1e9,
+            "achieved_gflops_per_gpu": 2.0 * local_rows * cols / (kernel_ms * 1e-3) / 1e9,
         },
     }
+    if multi is not None:
+        out["multi_gpu"] = multi
     traffic_file = os.path.join(REPO, "profiles", "traffic.json")
-    if os.path.exists(traffic_file) and n == 32768 and args.st == "f32":
+    if os.path.exists(traffic_file) and n == 32768 and args.st == "f32" and world == 1:
         with open(traffic_file) as f:
-            out["roofline"]["traffic"] = json.load(f).get("gemv_vec_bytes_per_launch")
+            recorded = json.load(f)
+        out["roofline"]["traffic"] = recorded.get("gemv_vec_bytes_per_launch")
+        out["roofline"]["traffic_source"] = (
+            f"replayed from {recorded.get('source')} (builder's rocprofv3 passes on this "
+            "kernel: 2 * FETCH_SIZE + WRITE_SIZE, separate --pmc runs); not measured in "
+            "this run")
 
     # ---- accuracy on rank 0: the reference's metric sum|ref - res| / sum|ref|
     # (gemv_benchmark.cu:101-124) against the fp64 kernel on the unrounded data

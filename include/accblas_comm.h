@@ -61,7 +61,12 @@ int accblas_comm_world_size(const accblas_comm *comm, int *world_size);
 int accblas_comm_device(const accblas_comm *comm, int *device);
 
 /* Single-process use: groups the collectives issued for several
- * communicators between begin and end (ncclGroupStart / ncclGroupEnd). */
+ * communicators between begin and end (ncclGroupStart / ncclGroupEnd). RCCL
+ * enqueues a grouped collective only at group end; work that must follow it
+ * on the stream (the cast of accblas_comm_acc_dot to a result type other than
+ * the arithmetic type) is enqueued by accblas_comm_group_end, after the
+ * collectives, so the results are valid once the streams have passed the
+ * group end. Begin and end must be called by the same host thread. */
 int accblas_comm_group_begin(void);
 int accblas_comm_group_end(void);
 
@@ -76,7 +81,11 @@ int accblas_shard_bounds(int64_t n, int world_size, int rank, int64_t align,
 
 /* dot over the union of the ranks' chunks: x, y are THIS rank's n_local
  * elements; on return (stream-ordered) every rank's device scalar `res`
- * (type res_t) holds the global sum. `handle` as in accblas_acc_dot. */
+ * (type res_t) holds the global sum. `handle` as in accblas_acc_dot. Stream
+ * order: chunk dot -> all-reduce of ONE element of type `ar` -> cast to res_t
+ * (none when res_t == ar: the all-reduce writes `res`). May be called inside a
+ * group (see accblas_comm_group_begin). ACCBLAS_COMM_FORCE_COLLECTIVE=1 in the
+ * environment makes a world of one rank run the collective as well (tests). */
 int accblas_comm_acc_dot(accblas_comm *comm, accblas_handle *handle,
                          accblas_dtype ar, accblas_dtype st,
                          accblas_dtype res_t, int64_t n_local, const void *x,

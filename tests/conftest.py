@@ -21,16 +21,23 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """A fresh checkout has no binaries: build them once (hipcc cross-compiles
-    without a GPU). On the GPU box the prebuilt files travel with the snapshot."""
+    """Builds the binaries when they are missing OR stale (hipcc cross-compiles
+    without a GPU): `make` stamps a hash of the sources beside the libraries
+    (tools/source_hash.py) and a tree whose hash differs is rebuilt, so the
+    prebuilt files that travel to the GPU box with the snapshot are always the
+    ones of this checkout."""
     import subprocess
     pkg = os.path.join(REPO, "accessor-blas_amd")
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from source_hash import source_hash
+    stamp = os.path.join(pkg, "lib", "SOURCE_HASH")
+    fresh = os.path.exists(stamp) and open(stamp).read().strip() == source_hash()
     wanted = [os.path.join(pkg, "lib", "libaccblas_hip.so"),
               os.path.join(pkg, "lib", "libaccblas_vendor.so"),
               os.path.join(pkg, "lib", "libaccblas_rccl.so"),
               os.path.join(pkg, "bin", "multi_gpu_benchmark"),
               os.path.join(pkg, "bin", "gemv_benchmark")]
-    if not all(os.path.exists(p) for p in wanted):
+    if not fresh or not all(os.path.exists(p) for p in wanted):
         subprocess.run(["make", "-C", pkg, "-j", str(min(8, os.cpu_count() or 1)), "all"],
                        check=True, stdout=subprocess.DEVNULL)
     if not os.path.exists(os.path.join(REPO, "oracle", "liboracle.so")):

@@ -162,8 +162,8 @@ def test_shard_bounds_properties():
         assert pieces[0][0] == 0 and pieces[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))
         assert all(lo <= hi for lo, hi in pieces)
+        assert pieces == [multi_gpu.shard_bounds(n, world, r, align) for r in range(world)]
         if align == 1:
-            assert pieces == [multi_gpu.shard_bounds(n, world, r) for r in range(world)]
             sizes = [hi - lo for lo, hi in pieces]
             assert max(sizes) - min(sizes) <= 1
         else:

@@ -103,3 +103,87 @@ def test_multi_gpu_driver_on_one_device():
     gemv = lines["GEMV Acc<fp64, fp32>"]
     assert gemv["all_ranks_identical"] == "yes"
     assert float(gemv["rel_err_sampled_rows"]) <= 1e-7
+
+
+def test_grouped_dot_casts_after_the_deferred_all_reduce(handle, monkeypatch):
+    """Inside accblas_comm_group_begin/_end RCCL only records the all-reduce and
+    enqueues it at group end; the cast to a result type other than the
+    arithmetic type must still come after it. ACCBLAS_COMM_FORCE_COLLECTIVE=1
+    makes the world of one rank run the real ncclAllReduce (partial slot ->
+    reduced slot), so a cast enqueued too early would read a stale slot."""
+    monkeypatch.setenv("ACCBLAS_COMM_FORCE_COLLECTIVE", "1")
+    torch.cuda.set_device(0)
+    (c,) = comm.Comm.create_all(1)
+    try:
+        gen = torch.Generator(device="cpu").manual_seed(21)
+        for n, seed_value in [(400_003, 5.0), (1_000_001, -3.0)]:
+            x = (torch.rand(n, generator=gen, dtype=torch.float64) * 2 - 1).float().to(DEV)
+            y = (torch.rand(n, generator=gen, dtype=torch.float64) * 2 - 1).float().to(DEV)
+            single = torch.zeros(1, dtype=torch.float32, device=DEV)
+            accblas.acc_dot(handle, accblas.F32, accblas.F32, accblas.F32, n, x, 1, y, 1, single)
+            narrow = torch.full((1,), seed_value, dtype=torch.float32, device=DEV)
+            wide = torch.full((1,), seed_value, dtype=torch.float64, device=DEV)
+            comm.group_begin()
+            c.acc_dot(handle, accblas.F32, accblas.F32, accblas.F64, n, x, 1, y, 1, wide)
+            comm.group_end()
+            comm.group_begin()
+            c.acc_dot(handle, accblas.F32, accblas.F32, accblas.F32, n, x, 1, y, 1, narrow)
+            comm.group_end()
+            torch.cuda.synchronize()
+            assert wide.item() == single.item() and narrow.item() == single.item()
+        # ungrouped calls take the same route
+        wide = torch.zeros(1, dtype=torch.float64, device=DEV)
+        c.acc_dot(handle, accblas.F32, accblas.F32, accblas.F64, n, x, 1, y, 1, wide)
+        torch.cuda.synchronize()
+        assert wide.item() == single.item()
+        # forced all-gather of the one slice
+        rows, cols = 128, 512
+        A = torch.rand(rows, cols, device=DEV)
+        xv = torch.rand(cols, device=DEV)
+        local = torch.zeros(rows, device=DEV)
+        full = torch.zeros(rows, device=DEV)
+        c.acc_gemv(accblas.F64, accblas.F32, rows, cols, 1.0, A, cols, xv, 1, 0.0, local, 1,
+                   res_full=full)
+        torch.cuda.synchronize()
+        assert torch.equal(full, local) and full.abs().sum().item() > 0
+    finally:
+        c.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
+def test_two_gpu_grouped_dot_and_gemv(monkeypatch):
+    """One process driving two communicators (accblas_comm_create_all): the
+    sharded dot (fp32 arithmetic, fp64 result: the cast follows the grouped
+    all-reduce) and the row-block GEMV with the all-gather. Runs wherever two
+    GPUs are visible (not on the one-GPU test box)."""
+    comms = comm.Comm.create_all(2)
+    try:
+        n = 1_000_003
+        gen = torch.Generator(device="cpu").manual_seed(31)
+        xs = (torch.rand(n, generator=gen, dtype=torch.float64) * 2 - 1).float()
+        ys = (torch.rand(n, generator=gen, dtype=torch.float64) * 2 - 1).float()
+        handles, results, keep = [], [], []
+        for c in comms:
+            torch.cuda.set_device(c.device)
+            handles.append(accblas.Handle())
+            results.append(torch.zeros(1, dtype=torch.float64, device=f"cuda:{c.device}"))
+        comm.group_begin()
+        for c, h, r in zip(comms, handles, results):
+            torch.cuda.set_device(c.device)
+            lo, hi = c.shard(n, 4)
+            x = xs[lo:hi].to(f"cuda:{c.device}")
+            y = ys[lo:hi].to(f"cuda:{c.device}")
+            keep += [x, y]
+            c.acc_dot(h, accblas.F32, accblas.F32, accblas.F64, hi - lo, x, 1, y, 1, r)
+        comm.group_end()
+        for c in comms:
+            torch.cuda.synchronize(c.device)
+        want = float((xs.double() * ys.double()).sum())
+        scale = float(((xs.double() * ys.double()) ** 2).sum().sqrt())
+        assert results[0].item() == results[1].item()
+        assert abs(results[0].item() - want) <= 64 * 2.0 ** -24 * scale
+        for h in handles:
+            h.close()
+    finally:
+        for c in comms:
+            c.close()
