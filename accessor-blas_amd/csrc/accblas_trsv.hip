@@ -6,89 +6,101 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include "accblas_trsv_common.hpp"
 
 
 namespace {
-std::atomic<int> trsv_split_option{0};
-std::atomic<int> trsv_wide_option{0};
+std::atomic<int> trsv_wide_option{1};
 std::atomic<int> trsv_relay_option{1};
 std::atomic<int> gemv_skew_option_store{1};
 }
 
 int accblas::gemv_skew_option_value() { return gemv_skew_option_store.load(); }
-
-bool accblas::trsv_split_enabled() { return trsv_split_option.load() != 0; }
-bool accblas::trsv_wide_enabled() { return trsv_wide_option.load() != 0; }
+int accblas::trsv_wide_option_value() { return trsv_wide_option.load(); }
 int accblas::trsv_relay_option_value() { return trsv_relay_option.load(); }
 
 extern "C" int accblas_set_option(const char *name, int value)
 {
-    if (name != nullptr && std::string(name) == "trsv_split") {
-        trsv_split_option.store(value);
-        return ACCBLAS_OK;
+    const std::string key = name != nullptr ? name : "";
+    std::atomic<int> *target = nullptr;
+    if (key == "trsv_wide") {
+        target = &trsv_wide_option;
+    } else if (key == "trsv_relay") {
+        target = &trsv_relay_option;
+    } else if (key == "gemv_skew") {
+        target = &gemv_skew_option_store;
+    } else {
+        return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
+                                  "accblas_set_option: unknown option");
     }
-    if (name != nullptr && std::string(name) == "trsv_wide") {
-        trsv_wide_option.store(value);
-        return ACCBLAS_OK;
+    if (value < 0 || value > 2) {
+        return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
+                                  key + " takes 0, 1 or 2");
     }
-    if (name != nullptr && std::string(name) == "trsv_relay") {
-        if (value < 0 || value > 2) {
-            return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
-                                      "trsv_relay takes 0, 1 or 2");
-        }
-        trsv_relay_option.store(value);
-        return ACCBLAS_OK;
-    }
-    if (name != nullptr && std::string(name) == "gemv_skew") {
-        if (value < 0 || value > 2) {
-            return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
-                                      "gemv_skew takes 0, 1 or 2");
-        }
-        gemv_skew_option_store.store(value);
-        return ACCBLAS_OK;
-    }
-    return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
-                              "accblas_set_option: unknown option");
-}
-
-int accblas::trsv_num_cus()
-{
-    static int cached = 0;
-    if (cached == 0) {
-        int device = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&device) == hipSuccess &&
-            hipGetDeviceProperties(&prop, device) == hipSuccess) {
-            cached = prop.multiProcessorCount;
-        } else {
-            cached = 1;
-        }
-    }
-    return cached;
+    target->store(value);
+    return ACCBLAS_OK;
 }
 
 
 namespace {
 
 
-// Hand-off workspace of the solve kernels: a 4 KiB header (the
-// `trsv_state` of `kernel::trsv`) followed by 8-byte {tag, value} granules, one or
-// two per element of x. The reference's launcher signature has no handle to
-// keep it in, so the library owns one buffer per (device, stream) and grows it
-// on demand; growth is the only time a TRSV call allocates (and synchronises
-// that stream first, so a solve still reading the old buffer finishes). A new
-// buffer is zeroed once; `kernel::trsv` re-arms it itself (epoch tags).
+// Hand-off workspace of the solve kernels: a 4 KiB header (the `trsv_state`
+// of the kernels) followed by 8-byte {tag, value} granules, one or two per
+// element of x. The reference's launcher signature has no handle to keep it
+// in (its `helper` is two words), so for the drop-in entry points the library
+// owns one buffer per (device, stream) and grows it on demand. Lifetime rules:
+//   * a buffer that was handed to a launch is never freed or re-used for
+//     anything else until accblas_trsv_release_workspace(stream): growth
+//     allocates a NEW buffer and retires the old one, so a hipGraph that
+//     captured a solve keeps replaying on memory that is still there (its
+//     own state word and granules; solves on different buffers of one stream
+//     do not interact);
+//   * the lock is held from "pointer taken" to "kernel enqueued"
+//     (`trsv_workspace_lease`);
+//   * growth needs hipMalloc + a memset: it is refused while the stream is
+//     being captured (run one eager solve of that size first, or pass your own
+//     workspace: accblas_acc_trsv_ws).
+// A new buffer is zeroed once; the kernels re-arm it themselves (epoch tags).
 struct workspace_entry {
     void *ptr{nullptr};
     std::size_t bytes{0};
+    std::vector<void *> retired;
 };
-
-constexpr std::size_t workspace_header_bytes = 4096;
 
 std::mutex workspace_guard;
 std::map<std::pair<int, hipStream_t>, workspace_entry> workspace_cache;
+
+int init_workspace(void *ptr, std::size_t bytes, hipStream_t stream)
+{
+    int status = accblas::check_hip(hipMemsetAsync(ptr, 0, bytes, stream),
+                                    "hipMemsetAsync(trsv workspace)");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    // header = accblas::dev::trsv_state{0, 0, first epoch, 0}; the source of
+    // the copy must outlive the asynchronous copy: static storage
+    static const accblas::dev::trsv_state initial{
+        0u, 0u, accblas::dev::trsv_first_epoch, 0u};
+    return accblas::check_hip(
+        hipMemcpyAsync(ptr, &initial, sizeof(initial), hipMemcpyHostToDevice,
+                       stream),
+        "hipMemcpyAsync(trsv state)");
+}
+
+accblas::dev::trsv_session session_of(void *ptr, std::size_t bytes)
+{
+    accblas::dev::trsv_session session{};
+    session.state = static_cast<accblas::dev::trsv_state *>(ptr);
+    session.granules = reinterpret_cast<accblas::dev::granule_word *>(
+        static_cast<char *>(ptr) + accblas::trsv_workspace_header_bytes);
+    session.capacity_words = static_cast<accblas::dev::index_type>(
+        (bytes - accblas::trsv_workspace_header_bytes) /
+        sizeof(accblas::dev::granule_word));
+    return session;
+}
 
 /** Caller holds `workspace_guard`. */
 int ensure_workspace(hipStream_t stream, std::size_t granule_bytes,
@@ -100,80 +112,52 @@ int ensure_workspace(hipStream_t stream, std::size_t granule_bytes,
         return status;
     }
     auto &entry = workspace_cache[std::make_pair(device, stream)];
-    const std::size_t bytes = granule_bytes + workspace_header_bytes;
+    const std::size_t bytes =
+        granule_bytes + accblas::trsv_workspace_header_bytes;
     if (entry.bytes < bytes) {
-        if (entry.ptr != nullptr) {
-            status = accblas::check_hip(hipStreamSynchronize(stream),
-                                        "hipStreamSynchronize");
-            if (status != ACCBLAS_OK) {
-                return status;
-            }
-            (void)hipFree(entry.ptr);
-            entry = workspace_entry{};
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &capture) == hipSuccess &&
+            capture != hipStreamCaptureStatusNone) {
+            return accblas::set_error(
+                ACCBLAS_ERR_INVALID_ARGUMENT,
+                "trsv: the library-owned workspace of this stream would have "
+                "to grow during stream capture; run one eager solve of this "
+                "size first or use accblas_acc_trsv_ws");
         }
         const std::size_t rounded =
             std::max<std::size_t>(bytes + bytes / 2, std::size_t{1} << 16);
-        status = accblas::check_hip(hipMalloc(&entry.ptr, rounded),
+        void *fresh = nullptr;
+        status = accblas::check_hip(hipMalloc(&fresh, rounded),
                                     "hipMalloc(trsv workspace)");
         if (status != ACCBLAS_OK) {
-            entry = workspace_entry{};
             return status;
         }
+        status = init_workspace(fresh, rounded, stream);
+        if (status != ACCBLAS_OK) {
+            (void)hipFree(fresh);
+            return status;
+        }
+        if (entry.ptr != nullptr) {
+            entry.retired.push_back(entry.ptr);
+        }
+        entry.ptr = fresh;
         entry.bytes = rounded;
-        status = accblas::check_hip(
-            hipMemsetAsync(entry.ptr, 0, rounded, stream),
-            "hipMemsetAsync(trsv workspace)");
-        if (status != ACCBLAS_OK) {
-            return status;
-        }
-        // header = accblas::dev::trsv_state{0, 0, first epoch, 0}
-        static const accblas::dev::trsv_state initial{
-            0u, 0u, accblas::dev::trsv_first_epoch, 0u};
-        status = accblas::check_hip(
-            hipMemcpyAsync(entry.ptr, &initial, sizeof(initial),
-                           hipMemcpyHostToDevice, stream),
-            "hipMemcpyAsync(trsv state)");
-        if (status != ACCBLAS_OK) {
-            return status;
-        }
     }
     *out = &entry;
     return ACCBLAS_OK;
 }
 
-accblas::dev::granule_word *granules_of(const workspace_entry &entry)
-{
-    return reinterpret_cast<accblas::dev::granule_word *>(
-        static_cast<char *>(entry.ptr) + workspace_header_bytes);
-}
-
 }  // namespace
 
 
-int accblas::trsv_get_workspace(hipStream_t stream, std::size_t bytes,
-                                accblas::dev::granule_word **out)
+int accblas::trsv_workspace_lease::acquire(hipStream_t stream,
+                                           std::size_t granule_bytes)
 {
-    std::lock_guard<std::mutex> lock(workspace_guard);
+    lock_ = std::unique_lock<std::mutex>(workspace_guard);
     workspace_entry *entry = nullptr;
-    const int status = ensure_workspace(stream, bytes, &entry);
+    const int status = ensure_workspace(stream, granule_bytes, &entry);
     if (status == ACCBLAS_OK) {
-        *out = granules_of(*entry);
-    }
-    return status;
-}
-
-int accblas::trsv_get_session(hipStream_t stream, std::size_t bytes,
-                              accblas::dev::trsv_session *out)
-{
-    std::lock_guard<std::mutex> lock(workspace_guard);
-    workspace_entry *entry = nullptr;
-    const int status = ensure_workspace(stream, bytes, &entry);
-    if (status == ACCBLAS_OK) {
-        out->state = static_cast<accblas::dev::trsv_state *>(entry->ptr);
-        out->granules = granules_of(*entry);
-        out->capacity_words = static_cast<accblas::dev::index_type>(
-            (entry->bytes - workspace_header_bytes) /
-            sizeof(accblas::dev::granule_word));
+        session_ = session_of(entry->ptr, entry->bytes);
     }
     return status;
 }
@@ -221,6 +205,72 @@ int validate_trsv(accblas_uplo uplo, accblas_diag diag, int64_t n,
 }  // namespace
 
 
+namespace {
+
+
+template <typename St>
+std::size_t workspace_bytes_for(int64_t n)
+{
+    return accblas::trsv_workspace_total_bytes<St>(n);
+}
+
+int workspace_session(void *workspace, std::size_t workspace_bytes,
+                      accblas::dev::trsv_session *out)
+{
+    if (workspace == nullptr) {
+        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER,
+                                  "trsv: workspace is NULL");
+    }
+    if (workspace_bytes <= accblas::trsv_workspace_header_bytes ||
+        !accblas::dev::is_aligned(workspace, 512)) {
+        return accblas::set_error(
+            ACCBLAS_ERR_INVALID_ARGUMENT,
+            "trsv: workspace must be 512-byte aligned and larger than its "
+            "4 KiB header");
+    }
+    *out = session_of(workspace, workspace_bytes);
+    return ACCBLAS_OK;
+}
+
+int plain_trsv(accblas_dtype vt, accblas_uplo uplo, accblas_diag diag,
+               int64_t n, const void *A, int64_t lda, void *x, int64_t incx,
+               uint32_t *helper, void *stream,
+               const accblas::dev::trsv_session *external)
+{
+    return accblas::dispatch_arithmetic(vt, [&](auto tag) {
+        using value_type = typename decltype(tag)::type;
+        using namespace accblas::dev;
+        const plain_view<const value_type> m_view{
+            static_cast<const value_type *>(A), {n, n}, lda};
+        const plain_view<value_type> x_view{static_cast<value_type *>(x),
+                                            {n, 1}, incx};
+        return accblas::trsv_dispatch<value_type, value_type>(
+            uplo == ACCBLAS_UPPER, diag == ACCBLAS_UNIT, n, m_view, x_view,
+            helper, stream, external);
+    });
+}
+
+int acc_trsv_any(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
+                 accblas_diag diag, int64_t n, const void *A, int64_t lda,
+                 void *x, int64_t incx, uint32_t *helper, void *stream,
+                 const accblas::dev::trsv_session *external)
+{
+    if (ar == ACCBLAS_F32) {
+        return accblas::acc_trsv_f32(st, uplo, diag, n, A, lda, x, incx,
+                                     helper, stream, external);
+    }
+    if (ar == ACCBLAS_F64) {
+        return accblas::acc_trsv_f64(st, uplo, diag, n, A, lda, x, incx,
+                                     helper, stream, external);
+    }
+    return accblas::set_error(ACCBLAS_ERR_UNSUPPORTED_TYPES,
+                              "arithmetic type must be f32 or f64");
+}
+
+
+}  // namespace
+
+
 extern "C" {
 
 
@@ -232,17 +282,8 @@ int accblas_trsv(accblas_dtype vt, accblas_uplo uplo, accblas_diag diag,
     if (status != ACCBLAS_OK) {
         return status;
     }
-    return accblas::dispatch_arithmetic(vt, [&](auto tag) {
-        using value_type = typename decltype(tag)::type;
-        using namespace accblas::dev;
-        const plain_view<const value_type> m_view{
-            static_cast<const value_type *>(A), {n, n}, lda};
-        const plain_view<value_type> x_view{static_cast<value_type *>(x),
-                                            {n, 1}, incx};
-        return accblas::trsv_dispatch<value_type, value_type>(
-            uplo == ACCBLAS_UPPER, diag == ACCBLAS_UNIT, n, m_view, x_view,
-            helper, stream);
-    });
+    return plain_trsv(vt, uplo, diag, n, A, lda, x, incx, helper, stream,
+                      nullptr);
 }
 
 
@@ -254,16 +295,108 @@ int accblas_acc_trsv(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
     if (status != ACCBLAS_OK) {
         return status;
     }
-    if (ar == ACCBLAS_F32) {
-        return accblas::acc_trsv_f32(st, uplo, diag, n, A, lda, x, incx,
-                                     helper, stream);
+    return acc_trsv_any(ar, st, uplo, diag, n, A, lda, x, incx, helper, stream,
+                        nullptr);
+}
+
+
+int accblas_trsv_workspace_bytes(accblas_dtype st, int64_t n, size_t *bytes)
+{
+    if (bytes == nullptr) {
+        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER,
+                                  "trsv_workspace_bytes: bytes is NULL");
     }
-    if (ar == ACCBLAS_F64) {
-        return accblas::acc_trsv_f64(st, uplo, diag, n, A, lda, x, incx,
-                                     helper, stream);
+    if (n < 0) {
+        return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
+                                  "trsv_workspace_bytes: n < 0");
     }
-    return accblas::set_error(ACCBLAS_ERR_UNSUPPORTED_TYPES,
-                              "arithmetic type must be f32 or f64");
+    return accblas::dispatch_type(st, [&](auto tag) {
+        using st_type = typename decltype(tag)::type;
+        *bytes = workspace_bytes_for<st_type>(n);
+        return ACCBLAS_OK;
+    });
+}
+
+
+int accblas_trsv_workspace_init(void *workspace, size_t workspace_bytes,
+                                void *stream)
+{
+    accblas::dev::trsv_session session{};
+    const int status = workspace_session(workspace, workspace_bytes, &session);
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    return init_workspace(workspace, workspace_bytes,
+                          accblas::as_stream(stream));
+}
+
+
+int accblas_trsv_ws(accblas_dtype vt, accblas_uplo uplo, accblas_diag diag,
+                    int64_t n, const void *A, int64_t lda, void *x,
+                    int64_t incx, uint32_t *helper, void *workspace,
+                    size_t workspace_bytes, void *stream)
+{
+    int status = validate_trsv(uplo, diag, n, A, lda, x, incx, helper);
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    accblas::dev::trsv_session session{};
+    status = workspace_session(workspace, workspace_bytes, &session);
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    return plain_trsv(vt, uplo, diag, n, A, lda, x, incx, helper, stream,
+                      &session);
+}
+
+
+int accblas_acc_trsv_ws(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
+                        accblas_diag diag, int64_t n, const void *A,
+                        int64_t lda, void *x, int64_t incx, uint32_t *helper,
+                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    int status = validate_trsv(uplo, diag, n, A, lda, x, incx, helper);
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    accblas::dev::trsv_session session{};
+    status = workspace_session(workspace, workspace_bytes, &session);
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    return acc_trsv_any(ar, st, uplo, diag, n, A, lda, x, incx, helper, stream,
+                        &session);
+}
+
+
+int accblas_trsv_release_workspace(void *stream)
+{
+    std::lock_guard<std::mutex> lock(workspace_guard);
+    int device = 0;
+    int status = accblas::check_hip(hipGetDevice(&device), "hipGetDevice");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    const auto found =
+        workspace_cache.find(std::make_pair(device, accblas::as_stream(stream)));
+    if (found == workspace_cache.end()) {
+        return ACCBLAS_OK;
+    }
+    // solves still running on these buffers finish first
+    status = accblas::check_hip(
+        hipStreamSynchronize(accblas::as_stream(stream)),
+        "hipStreamSynchronize");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    for (void *old : found->second.retired) {
+        (void)hipFree(old);
+    }
+    if (found->second.ptr != nullptr) {
+        (void)hipFree(found->second.ptr);
+    }
+    workspace_cache.erase(found);
+    return ACCBLAS_OK;
 }
 
 

@@ -1,5 +1,6 @@
-// Shared pieces of the TRSV C-ABI translation units. The 64 kernel variants
-// (uplo x diag x vector/scalar x 8 type pairs) are split over three TUs
+// Shared pieces of the TRSV C-ABI translation units. The kernel variants
+// (uplo x diag x {64-row vector / scalar / relay, 128-row} x 8 type pairs) are
+// split over three TUs
 // (accblas_trsv.hip: plain + entry points, accblas_trsv_f32.hip /
 // accblas_trsv_f64.hip: accessor kernels by arithmetic type) so that they
 // compile in parallel.
@@ -8,81 +9,105 @@
 #include <array>
 #include <cstdint>
 
+#include <mutex>
+
 #include "accblas_internal.hpp"
 #include "trsv_kernels.hpp"
-#include "trsv_split_kernels.hpp"
 #include "trsv_wide_kernels.hpp"
 
 
 namespace accblas {
 
 
-/** Hand-off workspace (8-byte granules) owned by the library per (device,
- *  stream); defined in accblas_trsv.hip. */
-int trsv_get_workspace(hipStream_t stream, std::size_t bytes,
-                       dev::granule_word **out);
+/** Bytes in front of the granules of a TRSV workspace (holds `trsv_state`). */
+constexpr std::size_t trsv_workspace_header_bytes = 4096;
 
-/** The same workspace as `kernel::trsv` sees it (state header + granules). */
-int trsv_get_session(hipStream_t stream, std::size_t bytes,
-                     dev::trsv_session *out);
+/** Total bytes of a workspace for n unknowns of storage type St. */
+template <typename St>
+constexpr std::size_t trsv_workspace_total_bytes(int64_t n)
+{
+    return trsv_workspace_header_bytes + dev::trsv_workspace_bytes<St>(n);
+}
 
-/** Compute units of the current device (cached). */
-int trsv_num_cus();
+/**
+ * The library-owned hand-off workspace of a (device, stream), leased for the
+ * duration of one launch: the lock is held until the lease is dropped, so
+ * another host thread cannot grow (and retire) the buffer between "pointer
+ * taken" and "kernel enqueued". Buffers that were ever handed to a launch are
+ * never freed behind the caller's back: growth allocates a new one and
+ * retires the old one until `accblas_trsv_release_workspace` (defined in
+ * accblas_trsv.hip).
+ */
+class trsv_workspace_lease {
+public:
+    trsv_workspace_lease() = default;
+    trsv_workspace_lease(const trsv_workspace_lease &) = delete;
+    trsv_workspace_lease &operator=(const trsv_workspace_lease &) = delete;
 
-/** Options "trsv_split" / "trsv_wide" (accblas_set_option). */
-bool trsv_split_enabled();
-bool trsv_wide_enabled();
+    /** Status of include/accblas.h; on success `session()` is valid. */
+    int acquire(hipStream_t stream, std::size_t granule_bytes);
+    const dev::trsv_session &session() const { return session_; }
+
+private:
+    std::unique_lock<std::mutex> lock_;
+    dev::trsv_session session_{};
+};
+
+/** Option "trsv_wide": 0 = 64-row kernel only, 1 = 128-row kernel by the
+ *  measured rule (default), 2 = 128-row kernel whenever the operands allow. */
+int trsv_wide_option_value();
 /** Option "trsv_relay": 0 never, 1 by the measured rule (default), 2 always. */
 int trsv_relay_option_value();
 
+/** From this size on the 128-row kernel is the faster one
+ *  (profiles/r02_trsv_wide_ab.txt). */
+#ifndef ACCBLAS_TRSV_WIDE_MIN_N
+#define ACCBLAS_TRSV_WIDE_MIN_N 4096
+#endif
 
-/** Picks the role-split kernel for large aligned systems, `kernel::trsv`
- *  otherwise, and launches. */
+
+/**
+ * Picks the kernel and launches: `kernel::trsv_wide` (128-row blocks) for
+ * large aligned systems, `kernel::trsv` otherwise. `external` = a
+ * caller-owned, initialised workspace (accblas_*_trsv_ws) or NULL for the
+ * library-owned one of the stream.
+ */
 template <typename ar_type, typename st_type, typename MtxView, typename XView>
 int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
-                  const XView &x, uint32_t *helper, void *stream)
+                  const XView &x, uint32_t *helper, void *stream,
+                  const dev::trsv_session *external = nullptr)
 {
     if (n <= 0) {
         return ACCBLAS_OK;
     }
-    const std::size_t bytes =
-        std::max(dev::trsv_workspace_bytes<st_type>(n),
-                 dev::trsv_split_workspace_bytes<ar_type, st_type>(n));
-    // the opt-in kernels keep the two-launch protocol (trsv_init zeroes the
-    // granules before every solve)
-    if (trsv_wide_enabled() || trsv_split_enabled()) {
-        dev::granule_word *granules = nullptr;
-        const int ws_status =
-            trsv_get_workspace(as_stream(stream), bytes, &granules);
-        if (ws_status != ACCBLAS_OK) {
-            return ws_status;
-        }
-        bool launched = false;
-        if (trsv_wide_enabled()) {
-            const int wide_status = check_hip(
-                dev::try_launch_trsv_wide<ar_type>(upper, unit_diag, mtx, x,
-                                                   helper, granules,
-                                                   as_stream(stream), &launched),
-                "trsv (128-row) launch");
-            if (wide_status != ACCBLAS_OK || launched) {
-                return wide_status;
-            }
-        }
-        if (trsv_split_enabled()) {
-            const int split_status = check_hip(
-                dev::try_launch_trsv_split<ar_type>(
-                    upper, unit_diag, mtx, x, helper, granules, trsv_num_cus(),
-                    as_stream(stream), &launched),
-                "trsv (split) launch");
-            if (split_status != ACCBLAS_OK || launched) {
-                return split_status;
-            }
-        }
-    }
+    const std::size_t bytes = dev::trsv_workspace_bytes<st_type>(n);
+    trsv_workspace_lease lease;
     dev::trsv_session session{};
-    const int status = trsv_get_session(as_stream(stream), bytes, &session);
-    if (status != ACCBLAS_OK) {
-        return status;
+    if (external != nullptr) {
+        if (static_cast<std::size_t>(external->capacity_words) *
+                sizeof(dev::granule_word) <
+            bytes) {
+            return set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
+                             "trsv: workspace smaller than "
+                             "accblas_trsv_workspace_bytes(st, n)");
+        }
+        session = *external;
+    } else {
+        const int status = lease.acquire(as_stream(stream), bytes);
+        if (status != ACCBLAS_OK) {
+            return status;
+        }
+        session = lease.session();
+    }
+    const int wide = trsv_wide_option_value();
+    const bool use_wide =
+        wide != 0 && dev::trsv_wide_applicable(upper, mtx) &&
+        (wide == 2 || n >= ACCBLAS_TRSV_WIDE_MIN_N);
+    if (use_wide) {
+        return check_hip(
+            dev::launch_trsv_wide<ar_type>(upper, unit_diag, mtx, x, helper,
+                                           session, as_stream(stream)),
+            "trsv (128-row) launch");
     }
     return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x, helper,
                                                session, as_stream(stream),
@@ -93,16 +118,19 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
 /** acc_trsv for one arithmetic type, all storage types. */
 int acc_trsv_f32(accblas_dtype st, accblas_uplo uplo, accblas_diag diag,
                  int64_t n, const void *A, int64_t lda, void *x, int64_t incx,
-                 uint32_t *helper, void *stream);
+                 uint32_t *helper, void *stream,
+                 const dev::trsv_session *external);
 int acc_trsv_f64(accblas_dtype st, accblas_uplo uplo, accblas_diag diag,
                  int64_t n, const void *A, int64_t lda, void *x, int64_t incx,
-                 uint32_t *helper, void *stream);
+                 uint32_t *helper, void *stream,
+                 const dev::trsv_session *external);
 
 
 template <typename ar_type>
 int acc_trsv_typed(accblas_dtype st, accblas_uplo uplo, accblas_diag diag,
                    int64_t n, const void *A, int64_t lda, void *x,
-                   int64_t incx, uint32_t *helper, void *stream)
+                   int64_t incx, uint32_t *helper, void *stream,
+                   const dev::trsv_session *external)
 {
     return dispatch_type(st, [&](auto st_tag) {
         using st_type = typename decltype(st_tag)::type;
@@ -121,7 +149,7 @@ int acc_trsv_typed(accblas_dtype st, accblas_uplo uplo, accblas_diag diag,
                                  stride_array{{incx}});
         return trsv_dispatch<ar_type, st_type>(uplo == ACCBLAS_UPPER,
                                                diag == ACCBLAS_UNIT, n, m_acc,
-                                               x_acc, helper, stream);
+                                               x_acc, helper, stream, external);
     });
 }
 

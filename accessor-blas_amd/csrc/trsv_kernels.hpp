@@ -121,7 +121,11 @@ struct trsv_state {
     unsigned int next_ticket;
     unsigned int finished;
     unsigned int epoch;
-    unsigned int reserved;
+    // `kernel::trsv_wide` only: number of leading 128-row blocks whose
+    // solution the next block's poller has read back from memory (monotone
+    // within a solve, 0 between solves). Workgroups far behind the chain's front wait on this
+    // one word instead of re-reading the granules they need.
+    unsigned int front;
 };
 
 constexpr unsigned int trsv_first_epoch = 2;
@@ -1065,6 +1069,8 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
             __hip_atomic_store(&session.state->next_ticket, 0u,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&session.state->finished, 0u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&session.state->front, 0u, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&session.state->epoch, next_epoch,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1,24 +1,37 @@
-// TRSV with 128-row blocks for gfx950 (large, 16-byte-aligned systems).
+// TRSV with 128-row blocks for gfx950: the kernel for large systems.
 //
-// Same maths, ticket scheduling, granule hand-off and accessor contract as
-// `kernel::trsv` (trsv_kernels.hpp; reference:
-// `/root/reference/cuda/trsv_kernels.cuh:527-692,725-893`). The solve is a
-// chain of dependent hops through memory (>= 0.5 us each on MI355X, ~1.2-2 us
-// with the work that sits on the path). `kernel::trsv` needs n/64 of them;
-// this kernel needs n/128, with the same amount of work on the path per hop:
-//   * a workgroup of 8 waves owns 128 rows; its diagonal tile
-//     T = [D00 0; D10 D11] is inverted blockwise (two 64 x 64 inversions by two
-//     waves at the same time, then X10 = -inv(D11) D10 inv(D00) by everybody);
+// Same maths, ticket scheduling, epoch-tagged granule hand-off, one launch per
+// solve and accessor contract as `kernel::trsv` (trsv_kernels.hpp; reference:
+// `/root/reference/cuda/trsv_kernels.cuh:527-692,725-893`). What changes is
+// how much of the dependency chain runs through memory. The solve is a chain
+// of hops "x_{b-1} published -> x_b published"; with 64-row blocks every hop
+// pays one store -> load round trip through the memory system (0.5 us idle,
+// 1-1.5 us beside the solve's own 16 KB-per-block-per-hop load bursts) plus
+// ~0.7 us of on-CU work, and rocprofv3 shows the traffic is exactly the
+// algorithmic bytes (profiles/r02_trsv_pmc_r01_kernel.json): the time goes
+// into the number of round trips, not into wasted bytes. This kernel halves
+// them without putting a second sequential step on the CU:
+//   * a workgroup of 8 waves owns 128 rows. Its diagonal block
+//     T = [D00 0; D10 D11] is inverted completely: the two 64 x 64 tiles by two
+//     teams of four waves at the same time (`detail::invert_tile64`), then
+//     X10 = -X11 (D10 X00) as two 64 x 64 x 64 products on the matrix cores;
 //   * the 128 x 128 panel next to the diagonal is folded with the inverse,
-//     W = inv(T) A_{b,b-1}, so x_b = inv(T) rhs_far - W x_{b-1};
-//   * W lives in REGISTERS, distributed over the workgroup: thread (half h,
-//     column group g, lane l) holds 32 consecutive entries of row 64 h + l
-//     (64 VGPRs for fp64). The 128 x 128 mat-vec on the critical path is then
-//     32 register-fed FMAs per thread (vector entries broadcast from LDS) plus
-//     one LDS combine over the 4 column groups; inv(T) stays in LDS as three
-//     64 x 64 tiles (a 128 x 128 fp64 tile alone would be 128 KiB);
-//   * far panels (128 columns wide): 16 rows per wave, 16-byte loads, double
-//     buffered with the x granules, one cross-lane reduction at the end.
+//     W = inv(T) A_{b,b-1} (a 128^3 product on the matrix cores, the panel
+//     passing through LDS in four chunks of 32 rows), so
+//     x_b = inv(T) rhs_far - W x_{b-1}: BOTH 64-row halves of x_b follow from
+//     x_{b-1} in one step, there is no hop between them;
+//   * W is computed TRANSPOSED (W^T = A^T inv(T)^T), which leaves it in the
+//     matrix cores' result layout exactly as the mat-vec wants it: wave w
+//     holds rows 16w .. 16w+15 of W, a row's 128 entries spread over four
+//     lanes of that wave (32 registers each). After x_{b-1} arrives every
+//     wave does 32 register-fed FMAs per lane and two cross-lane adds and
+//     publishes its own 16 rows: ONE barrier on the critical path (the
+//     hand-over of x_{b-1} through LDS), no cross-wave combine;
+//   * inv(T) stays in LDS (three 64 x 64 tiles) for c = inv(T) rhs_far, which
+//     is computed in the same lane layout before the wait;
+//   * far panels: 16 rows per wave, 16-byte loads of the storage type,
+//     `Depth` panels in flight per wave together with their x granules, FMA
+//     in the arithmetic type, one cross-lane reduction at the end.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -30,18 +43,74 @@ namespace accblas {
 namespace dev {
 
 
-constexpr int trsv_wide_tile = 128;
+constexpr int trsv_wide_rows = 128;
 constexpr int trsv_wide_waves = 8;
-constexpr index_type trsv_wide_min_n = 4096;
+
+
+// Diagnostic builds only (tools/tune_trsv_wide.hip defines
+// ACCBLAS_TRSV_WIDE_DIAG): every wave keeps 100 MHz wall-clock stamps of its
+// phases in registers and writes them out after it has published, so the
+// stamps cost no memory traffic while the block is on the chain. The library
+// is never built with it.
+#ifdef ACCBLAS_TRSV_WIDE_DIAG
+__device__ unsigned long long *trsv_wide_diag_buffer;
+#define ACCBLAS_TRSV_WIDE_STAMP(_slot) diag_stamp[_slot] = wall_clock64()
+#else
+#define ACCBLAS_TRSV_WIDE_STAMP(_slot) \
+    do {                               \
+    } while (false)
+#endif
 
 
 namespace kernel {
+namespace detail {
 
 
-template <bool Upper, bool UnitDiag, int Vec, typename ArType,
-          typename MtxView, typename XView>
+/** Where element `within` (0..15) of a 16-wide row of an MFMA result tile
+ *  lives: lane group `quad` (lane >> 4) and accumulator register `reg`, the
+ *  inverse of `mma_16x16x4<T>::row`. */
+template <typename T>
+struct mma_slot;
+
+template <>
+struct mma_slot<double> {
+    __device__ __forceinline__ static int quad(int within) { return within & 3; }
+    __device__ __forceinline__ static int reg(int within) { return within >> 2; }
+};
+
+template <>
+struct mma_slot<float> {
+    __device__ __forceinline__ static int quad(int within) { return within >> 2; }
+    __device__ __forceinline__ static int reg(int within) { return within & 3; }
+};
+
+
+/** Sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (all four end with it). */
+template <typename T>
+__device__ __forceinline__ T quad_column_sum(T value)
+{
+    value += __shfl_xor(value, 16, wave_size);
+    value += __shfl_xor(value, 32, wave_size);
+    return value;
+}
+
+
+}  // namespace detail
+
+
+/**
+ * Blocked triangular solve with 128-row blocks. blockDim = 512,
+ * grid = ceil(n / 128). Index mapping (`phys`), granule indexing, tags and
+ * the workspace protocol are those of `kernel::trsv`; both kernels can share
+ * one workspace. Vec = elements per 16-byte load (the matrix base and row
+ * stride must be 16-byte aligned, for Upper n % Vec == 0). PanelCols = columns
+ * a wave sweeps per step (128, or 64 to halve the registers of a stage),
+ * Depth = steps in flight per wave.
+ */
+template <bool Upper, bool UnitDiag, int Vec, int PanelCols, int Depth,
+          typename ArType, typename MtxView, typename XView>
 __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
-    MtxView mtx, XView x, std::uint32_t *helper, granule_word *granules)
+    MtxView mtx, XView x, std::uint32_t *helper, trsv_session session)
 {
     using ar_type = decltype(mtx(0, 0) * x(0, 0));
     static_assert(std::is_same<ArType, ar_type>::value,
@@ -50,198 +119,277 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     using x_traits = view_traits<XView>;
     using st_type = std::remove_cv_t<typename x_traits::storage_type>;
     using io = detail::granule_io<st_type>;
-    constexpr int T = trsv_wide_tile;   // rows per block
-    constexpr int H = T / 2;            // 64: half tile = wave width
-    constexpr int ld = H + 1;           // LDS leading dimension of 64x64 tiles
+    using mma = detail::mma_16x16x4<ar_type>;
+    using slot = detail::mma_slot<ar_type>;
+    constexpr int R = trsv_wide_rows;    // rows per block
+    constexpr int H = trsv_tile;         // 64: tile edge
+    constexpr int ld = H + 1;            // LDS leading dimension of a tile
     constexpr int Waves = trsv_wide_waves;
-    constexpr int G = Waves / 2;        // column groups per half (4)
-    constexpr int CG = T / G;           // columns per group (32)
-    constexpr int RW = T / Waves;       // rows per wave in the far sweep (16)
-    constexpr int LPR = T / Vec;        // lanes sharing one panel row
+    constexpr int RW = R / Waves;        // 16 rows per wave (sweep and W)
+    constexpr int LPR = PanelCols / Vec;  // lanes sharing one panel row
     constexpr int RPI = wave_size / LPR;  // rows per load instruction
-    constexpr int NI = RW / RPI;        // load instructions per panel
-    static_assert(Vec > 1 && LPR <= wave_size && RW % RPI == 0, "bad Vec");
+    constexpr int NI = RW / RPI;          // load instructions per step
+    constexpr int PPB = R / PanelCols;    // sweep steps per 128 columns
+    static_assert(Vec > 1 && (PanelCols == 64 || PanelCols == 128) &&
+                      LPR <= wave_size && RW % RPI == 0 && Depth >= 1,
+                  "bad sweep shape");
+    static_assert(RW == 16, "a wave owns one 16-row tile of W");
 
-    // four 64x64 staging tiles; the last one doubles as the panel chunk buffer
-    __shared__ ar_type buf[4][H * ld];
-    __shared__ ar_type correction[T];
-    __shared__ ar_type own_lds[T];
-    __shared__ ar_type x_prev_lds[T];
-    __shared__ ar_type part[Waves * H];
+    // tiles[0] = D00 -> X00, tiles[1] = D11 -> X11 (inverses column-major,
+    // tile[c * ld + r]), tiles[2] = D10 (row-major) -> X10 (column-major),
+    // tiles[3] = scratch: inversion, Y = D10 X00, panel chunks
+    __shared__ ar_type tiles[4][H * ld];
+    __shared__ ar_type own_lds[R];
+    __shared__ ar_type rhs_lds[R];   // own - far correction
+    // x_{b-3} / x_{b-2}, handed over by the one poller (two buffers in turn)
+    __shared__ __attribute__((aligned(16))) ar_type x_far[2][R];
+    __shared__ __attribute__((aligned(16))) st_type x_perm[R];    // x_{b-1} in the order the lanes read it
     __shared__ std::int32_t shared_block;
+    __shared__ std::uint32_t shared_epoch;
+    __shared__ std::uint32_t shared_front;  // newest `trsv_state::front` seen
+    __shared__ bool is_last;
 
     const int lane = lane_id();
-    const int wave = wave_id();
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int half = wave_u / G;      // 0: rows 0..63, 1: rows 64..127
-    const int group = wave_u % G;     // column group of this wave
-    const int row = half * H + lane;  // tile-local row of this thread
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave_id());
+#ifdef ACCBLAS_TRSV_WIDE_DIAG
+    unsigned long long diag_stamp[12] = {};
+#endif
+    ACCBLAS_TRSV_WIDE_STAMP(0);  // kernel entry
+    const int fi = lane & 15;  // MFMA fragment row (A) / column (B, D)
+    const int fk = lane >> 4;  // MFMA fragment k / lane group of a W row
     const index_type n = mtx.length(0);
+    granule_word *const granules = session.granules;
 
     if (threadIdx.x == 0) {
-        shared_block = static_cast<std::int32_t>(
-            __hip_atomic_fetch_add(helper + 1, 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT));
+        const unsigned int ticket = __hip_atomic_fetch_add(
+            &session.state->next_ticket, 1u, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+        shared_epoch = __hip_atomic_load(&session.state->epoch,
+                                         __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+        shared_block = static_cast<std::int32_t>(ticket);
+        shared_front = 0;
+        if (ticket == 0) {
+            // `trsv_init` (cuda/trsv_kernels.cuh:38-42) folded into the first
+            // block, as in `kernel::trsv`
+            __hip_atomic_store(helper, ~std::uint32_t{0}, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            helper[1] = static_cast<std::uint32_t>(ceildiv(n, index_type{H}));
+        }
     }
     __syncthreads();
     const index_type block = shared_block;
-    const index_type base = block * T;
+    const std::uint32_t epoch = shared_epoch;
+    const index_type base = block * R;
     if (base >= n) {
-        return;
+        return;  // cannot happen: the grid has exactly ceil(n / R) blocks
     }
     const auto phys = [n](index_type logical) {
         return Upper ? n - 1 - logical : logical;
+    };
+    // element (logical row gr, logical column gc), 0 for rows that do not exist
+    const auto entry = [&](index_type gr, index_type gc) -> ar_type {
+        return gr < n ? ar_type(mtx(phys(gr), phys(gc))) : ar_type{};
     };
     const st_type *a_data = mtx_traits::data(mtx);
     const index_type lda = mtx_traits::stride(mtx);
     st_type *x_data = x_traits::data(x);
     const index_type x_inc = x_traits::stride(x);
-    // element (logical row gr, logical column gc) of the matrix, 0 if the row
-    // does not exist
-    const auto entry = [&](index_type gr, index_type gc) {
-        return gr < n ? ar_type(mtx(phys(gr), phys(gc))) : ar_type{};
-    };
 
-    const index_type own_row = base + row;
-    const bool own_valid = own_row < n;
-    st_type *own_addr = x_data + phys(own_valid ? own_row : n - 1) * x_inc;
-    ar_type own_rhs{};
-    if (own_valid) {
-        own_rhs = static_cast<ar_type>(*own_addr);
-    }
-    if (group == 0) {
-        own_lds[row] = own_rhs;  // read after the barriers below
+    // this block's right-hand side (never written by another workgroup)
+    if (threadIdx.x < R) {
+        const index_type row = base + threadIdx.x;
+        own_lds[threadIdx.x] = row < n ? ar_type(x_data[phys(row) * x_inc])
+                                       : ar_type{};
     }
 
-    // ---- stage D00 -> buf[0], D11 -> buf[1] (row-major, diagonal tiles) and
-    //      D10 -> buf[2] (row-major) ------------------------------------------
-    for (int r = wave; r < H; r += Waves) {
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const index_type gr = base + d * H + r;
-            const index_type gc = base + d * H + lane;
-            ar_type value{};
-            if (lane == r) {
-                value = (UnitDiag || gr >= n) ? ar_type{1} : entry(gr, gc);
-            } else if (lane < r) {
-                value = entry(gr, gc);
-            }
-            buf[d][r * ld + lane] = value;
-        }
-        buf[2][r * ld + lane] = entry(base + H + r, base + lane);
-    }
-    __syncthreads();
-
-    // ---- invert the two diagonal tiles (waves 0 and G), lane = column -------
-    if (wave_u == 0 || wave_u == G) {
-        ar_type *tile = buf[wave_u == 0 ? 0 : 1];
-        ar_type column[H];
-#pragma unroll
-        for (int i = 0; i < H; ++i) {
-            ar_type sums[4] = {};
-#pragma unroll
-            for (int k = 0; k < i; ++k) {
-                sums[k & 3] += tile[i * ld + k] * column[k];
-            }
-            ar_type value = ((lane == i) ? ar_type{1} : ar_type{0}) -
-                            ((sums[0] + sums[1]) + (sums[2] + sums[3]));
-            if (!UnitDiag) {
-                value = value / tile[i * ld + i];
-            }
-            column[i] = value;
-        }
-#pragma unroll
-        for (int i = 0; i < H; ++i) {
-            tile[lane * ld + i] = column[i];  // inverse, column-major
-        }
-    }
-    __syncthreads();
-
-    // ---- X10 = -inv(D11) * D10 * inv(D00), 8 output columns per wave -------
-    // inv(D00)[k][j] = buf[0][j*ld + k], inv(D11)[i][k] = buf[1][k*ld + i]
+    // ---- stage D00, D11, D10 (a wave reads one tile row per load) ----------
     {
-        constexpr int OC = H / Waves;  // 8
-        const int j0 = wave_u * OC;
-        ar_type y[OC];
+        constexpr int RS = H / Waves;  // tile rows a wave stages
+        ar_type d00[RS], d11[RS], d10[RS];
 #pragma unroll
-        for (int q = 0; q < OC; ++q) {
-            y[q] = ar_type{};
-        }
-#pragma unroll 8
-        for (int k = 0; k < H; ++k) {
-            const ar_type d = buf[2][lane * ld + k];  // D10[i = lane][k]
-#pragma unroll
-            for (int q = 0; q < OC; ++q) {
-                y[q] += d * buf[0][(j0 + q) * ld + k];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < OC; ++q) {
-            buf[3][(j0 + q) * ld + lane] = y[q];  // Y = D10 inv(D00), col-major
-        }
-        __syncthreads();
-        ar_type z[OC];
-#pragma unroll
-        for (int q = 0; q < OC; ++q) {
-            z[q] = ar_type{};
-        }
-#pragma unroll 8
-        for (int k = 0; k < H; ++k) {
-            const ar_type d = buf[1][k * ld + lane];  // inv(D11)[i = lane][k]
-#pragma unroll
-            for (int q = 0; q < OC; ++q) {
-                z[q] -= d * buf[3][(j0 + q) * ld + k];
-            }
+        for (int i = 0; i < RS; ++i) {
+            const int r = wave_u + i * Waves;
+            const auto diag_entry = [&](index_type gr, index_type gc) {
+                if (lane == r) {
+                    return (UnitDiag || gr >= n) ? ar_type{1} : entry(gr, gc);
+                }
+                return lane < r ? entry(gr, gc) : ar_type{};
+            };
+            d00[i] = diag_entry(base + r, base + lane);
+            d11[i] = diag_entry(base + H + r, base + H + lane);
+            d10[i] = entry(base + H + r, base + lane);
         }
 #pragma unroll
-        for (int q = 0; q < OC; ++q) {
-            buf[2][(j0 + q) * ld + lane] = z[q];  // X10, col-major (D10 is dead)
+        for (int i = 0; i < RS; ++i) {
+            const int r = wave_u + i * Waves;
+            tiles[0][r * ld + lane] = d00[i];
+            tiles[1][r * ld + lane] = d11[i];
+            tiles[2][r * ld + lane] = d10[i];
         }
     }
     __syncthreads();
 
-    // inv(T)[r][k] for this thread's row r (tile-local) and any column k
-    const auto inv_entry = [&](int k) -> ar_type {
-        if (half == 0) {
-            return k < H ? buf[0][k * ld + lane] : ar_type{};
-        }
-        return k < H ? buf[2][k * ld + lane] : buf[1][(k - H) * ld + lane];
-    };
+    // ---- invert D00 (even waves) and D11 (odd waves) at the same time -------
+    // (the serial 16 x 16 substitutions run on team wave 0 = waves 0 and 1,
+    // which sit on different SIMDs)
+    {
+        const int team = wave_u % 2;
+        ar_type *scratch = tiles[3] + team * 1024;
+        detail::invert_tile64<UnitDiag>(tiles[team], scratch, scratch + 512,
+                                        wave_u / 2, lane,
+                                        (wave_u / 2) * wave_size + lane, 256);
+    }
+    __syncthreads();
 
-    // ---- W = inv(T) * A_{b,b-1}: this thread's 32 entries --------------------
-    ar_type w_reg[CG];
+    // ---- X10 = -X11 (D10 X00): 16 output tiles, two per wave ---------------
+    {
+        const int tj = wave_u % 4;
+        const int ti_of[2] = {wave_u / 4, 3 - wave_u / 4};
+        typename mma::acc_type y[2];
 #pragma unroll
-    for (int q = 0; q < CG; ++q) {
-        w_reg[q] = ar_type{};
+        for (int t = 0; t < 2; ++t) {
+            const int ti = ti_of[t];
+            // X00 is lower triangular: rows above column tile tj are zero
+            y[t] = detail::mma_tile_product<ar_type>(
+                16 * tj, H, fk,
+                [&](int k) { return tiles[2][(16 * ti + fi) * ld + k]; },
+                [&](int k) { return tiles[0][(16 * tj + fi) * ld + k]; });
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                tiles[3][(16 * ti_of[t] + mma::row(lane, reg)) * ld + 16 * tj +
+                         fi] = y[t][reg];
+            }
+        }
+        __syncthreads();  // Y complete, D10 used up
+        typename mma::acc_type z[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ti = ti_of[t];
+            // X11 is lower triangular: columns beyond row tile ti are zero
+            z[t] = detail::mma_tile_product<ar_type>(
+                0, 16 * (ti + 1), fk,
+                [&](int k) { return tiles[1][k * ld + 16 * ti + fi]; },
+                [&](int k) { return tiles[3][k * ld + 16 * tj + fi]; });
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                tiles[2][(16 * tj + fi) * ld + 16 * ti_of[t] +
+                         mma::row(lane, reg)] = -z[t][reg];
+            }
+        }
+    }
+    // readers of X10 and the next writers of tiles[3] wait at the barriers of
+    // the chunk loop below
+
+    // inv(T)[row][k] for k <= row < 128 (k > row: zero, stored for k in the
+    // row's own 64-column tile only)
+    const auto inv_entry = [&](int row, int k) -> ar_type {
+        if (row < H) {
+            return tiles[0][k * ld + row];
+        }
+        return k < H ? tiles[2][k * ld + row - H]
+                     : tiles[1][(k - H) * ld + row - H];
+    };
+    // Row tile t of W / c costs t + 1 passes over inv(T) (lower triangular).
+    // Waves w and w + 4 share a SIMD (and its matrix core, which on gfx950
+    // runs fp64 at the vector rate): tiles w and 7 - w give every SIMD 9 passes
+    const int own_tile = wave_u < 4 ? wave_u : 11 - wave_u;
+    const int own_tile_row = RW * own_tile + fi;  // this lane's row of W / of c
+    const int k_end = RW * (own_tile + 1);        // inv(T) row tile stops here
+
+    // ---- W = inv(T) A_{b,b-1}, transposed product, wave w = rows 16w.. -----
+    // D[i][j] = sum_k P[k][16 tj + i] inv(T)[16 w + j][k] = W[16w + j][16tj + i]:
+    // lane l ends with W[16w + (l & 15)][16 tj + mma::row(l, reg)] in
+    // w_acc[tj][reg]. The panel P passes through tiles[3] in chunks of 32 rows.
+    typename mma::acc_type w_acc[R / 16];
+#pragma unroll
+    for (int tj = 0; tj < R / 16; ++tj) {
+        w_acc[tj] = typename mma::acc_type{};
     }
     if (block > 0) {
-        constexpr int KC = 32;  // panel rows per chunk: 32 x 128 values in buf[3]
-        ar_type *chunk = buf[3];
-        for (int k0 = 0; k0 < T; k0 += KC) {
-            __syncthreads();  // previous chunk (or Y) fully consumed
-            // 4096 values / 512 threads: rows wave*4 .. wave*4+3, two columns
+        constexpr int KC = 32;             // panel rows per chunk
+        constexpr int per_thread = KC * R / (Waves * wave_size);  // 8
+        ar_type *chunk = tiles[3];         // chunk[kl * R + c]
+        const index_type prev = base - R;
+        for (int k0 = 0; k0 < R; k0 += KC) {
+            ar_type staged[per_thread];
 #pragma unroll
-            for (int j = 0; j < KC / Waves; ++j) {
-                const int kl = wave_u * (KC / Waves) + j;
-                const index_type gr = base + k0 + kl;
-                chunk[kl * T + lane] = entry(gr, base - T + lane);
-                chunk[kl * T + H + lane] = entry(gr, base - T + H + lane);
+            for (int j = 0; j < per_thread; ++j) {
+                const int e = j * Waves * wave_size + threadIdx.x;
+                staged[j] = entry(base + k0 + e / R, prev + e % R);
+            }
+            __syncthreads();  // previous chunk (or Y / X10 writes) done
+#pragma unroll
+            for (int j = 0; j < per_thread; ++j) {
+                const int e = j * Waves * wave_size + threadIdx.x;
+                chunk[e] = staged[j];
             }
             __syncthreads();
-            if (half == 1 || k0 < H) {  // inv(T)[r][k] = 0 for r < 64 <= k
-                for (int kl = 0; kl < KC; ++kl) {
-                    const ar_type t = inv_entry(k0 + kl);
+            for (int kp = k0; kp < k0 + KC && kp < k_end; kp += 16) {
+                ar_type b[4];
 #pragma unroll
-                    for (int q = 0; q < CG; ++q) {
-                        w_reg[q] += t * chunk[kl * T + group * CG + q];
+                for (int q = 0; q < 4; ++q) {
+                    b[q] = inv_entry(own_tile_row, kp + q * 4 + fk);
+                }
+#pragma unroll
+                for (int tj = 0; tj < R / 16; ++tj) {
+                    ar_type a[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a[q] = chunk[(kp - k0 + q * 4 + fk) * R + 16 * tj + fi];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        w_acc[tj] = mma::step(a[q], b[q], w_acc[tj]);
                     }
                 }
             }
         }
     }
 
-    // ---- far sweep: correction = sum_{c < block-1} A[block][c] x_c ---------
-    const index_type far_end = block - 1;  // panels [0, far_end), 128 columns
+    ACCBLAS_TRSV_WIDE_STAMP(1);  // inverse and W ready
+    unsigned int spins = 0;
+    // One wave waits for the 128 granules of an earlier block, two per lane
+    // (`first + lane` and `first + 64 + lane`): `poll_begin` issues the first
+    // probe (so that it can be under way while the wave still has other work),
+    // `poll_finish` repeats it until both granules carry this solve's tag.
+    const auto poll_begin = [&](index_type first, granule_word (&raw0)[io::words],
+                                granule_word (&raw1)[io::words]) {
+        io::load(granules, first, raw0);
+        io::load(granules, first + H, raw1);
+    };
+    const auto poll_finish = [&](index_type first, granule_word (&raw0)[io::words],
+                                 granule_word (&raw1)[io::words]) {
+        while (!__all(io::ready(raw0, epoch) && io::ready(raw1, epoch)) &&
+               !detail::spin_expired(spins, helper)) {
+            io::load(granules, first, raw0);
+            io::load(granules, first + H, raw1);
+        }
+    };
+    // ---- far sweep: correction = sum_{c < 128 (block-1)} A[block][c] x_c ----
+    // Step cb covers columns [cb * PanelCols, (cb + 1) * PanelCols); load
+    // instruction k of a wave covers rows wave*RW + k*RPI + lane/LPR and Vec
+    // consecutive (logical) columns starting at (lane % LPR) * Vec.
+    // The waves sweep independently and poll the x granules they need
+    // themselves - except for the last `shared_columns` block columns
+    // (x_{b-4} .. x_{b-2}), published four to two hops before x_b is due:
+    // "x_{b-2} seen -> sums reduced -> c" is a two-hop path of the chain, a
+    // wave's own poll loop notices a publication one to two memory round trips
+    // late, and eight independent pollers made the path as long as the slowest
+    // of eight detections (timeline in profiles/r02_trsv_wide_timeline.txt).
+    // For those columns ONE wave polls and hands x over through LDS (two
+    // buffers in turn, one barrier per column); their matrix data is
+    // prefetched by the same register ring as every other step.
+    constexpr int shared_columns = 3;
+    const index_type far_end = (block - 1) * PPB;   // steps [0, far_end)
+    const index_type shared_begin =                  // steps fed through LDS
+        far_end > shared_columns * PPB ? far_end - shared_columns * PPB : 0;
     const int row_in_inst = lane / LPR;
     const int col_group = lane % LPR;
     struct stage {
@@ -255,7 +403,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         row_ptr[k] = a_data + phys(gr < n ? gr : n - 1) * lda;
     }
     const auto issue = [&](index_type cb, stage &s) {
-        const index_type first_col = cb * T + col_group * Vec;  // logical
+        const index_type first_col = cb * PanelCols + col_group * Vec;
+        // lowest memory column of the group (columns descend for Upper)
         const index_type mem_col =
             Upper ? n - 1 - (first_col + Vec - 1) : first_col;
 #pragma unroll
@@ -266,9 +415,11 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                 s.a[k][e] = v[e];
             }
         }
+        if (cb < shared_begin) {
 #pragma unroll
-        for (int e = 0; e < Vec; ++e) {
-            io::load(granules, first_col + e, s.xraw[e]);
+            for (int e = 0; e < Vec; ++e) {
+                io::load(granules, first_col + e, s.xraw[e]);
+            }
         }
     };
     ar_type acc[NI];
@@ -276,106 +427,247 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     for (int k = 0; k < NI; ++k) {
         acc[k] = ar_type{};
     }
-    unsigned int spins = 0;
     const auto consume = [&](index_type cb, stage &s) {
-        const index_type first_col = cb * T + col_group * Vec;
-        while (true) {
-            bool ok = true;
-#pragma unroll
-            for (int e = 0; e < Vec; ++e) {
-                ok = ok && io::ready(s.xraw[e]);
-            }
-            if (__all(ok) || detail::spin_expired(spins, helper)) {
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-            for (int e = 0; e < Vec; ++e) {
-                io::load(granules, first_col + e, s.xraw[e]);
-            }
-        }
+        const index_type first_col = cb * PanelCols + col_group * Vec;
         ar_type xv[Vec];
+        if (cb < shared_begin) {
+            while (true) {
+                bool ok = true;
 #pragma unroll
-        for (int e = 0; e < Vec; ++e) {
-            xv[e] = static_cast<ar_type>(io::decode(s.xraw[e]));
+                for (int e = 0; e < Vec; ++e) {
+                    ok = ok && io::ready(s.xraw[e], epoch);
+                }
+                if (__all(ok) || detail::spin_expired(spins, helper)) {
+                    break;
+                }
+                // This column is not published yet (this workgroup has caught
+                // up with the chain's front) and it is at least three hops
+                // from being due: wait for ONE word to move on, politely,
+                // instead of re-reading the granules. ~1500 waves re-reading
+                // the newest 1 KB of granules as fast as they could made those
+                // few cache lines a hot spot exactly where the next block's
+                // poller and the publisher's write-through need to get through
+                // (the hop grew from 0.7 us to 1.3-2 us with the number of
+                // resident workgroups).
+                const std::uint32_t wanted =
+                    static_cast<std::uint32_t>(cb / PPB) + 1;
+                while (true) {
+                    std::uint32_t front = __hip_atomic_load(
+                        &shared_front, __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (front < wanted) {
+                        __builtin_amdgcn_s_sleep(8);
+                        front = __hip_atomic_load(&session.state->front,
+                                                  __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) {
+                            __hip_atomic_fetch_max(&shared_front, front,
+                                                   __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    if (front >= wanted ||
+                        detail::spin_expired(spins, helper)) {
+                        break;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < Vec; ++e) {
+                    io::load(granules, first_col + e, s.xraw[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < Vec; ++e) {
+                xv[e] = static_cast<ar_type>(io::decode(s.xraw[e]));
+            }
+        } else {
+            const index_type column = cb / PPB;  // block column of the step
+            ar_type *x_buffer = x_far[column & 1];
+            if (cb % PPB == 0) {
+                // every wave has consumed all earlier steps when it gets
+                // here; the buffer was last read two columns ago, before the
+                // previous column's barrier
+                ACCBLAS_TRSV_WIDE_STAMP(10);  // at the shared column (last one stays)
+                if (wave_u == 0) {
+                    granule_word raw0[io::words];
+                    granule_word raw1[io::words];
+                    poll_begin(column * R + lane, raw0, raw1);
+                    poll_finish(column * R + lane, raw0, raw1);
+                    x_buffer[lane] = static_cast<ar_type>(io::decode(raw0));
+                    x_buffer[H + lane] = static_cast<ar_type>(io::decode(raw1));
+                    ACCBLAS_TRSV_WIDE_STAMP(11);  // shared column observed
+                }
+                __syncthreads();
+            }
+            const int offset =
+                static_cast<int>(cb % PPB) * PanelCols + col_group * Vec;
+#pragma unroll
+            for (int e = 0; e < Vec; ++e) {
+                xv[e] = x_buffer[offset + e];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
 #pragma unroll
             for (int e = 0; e < Vec; ++e) {
+                // memory element e of an Upper group is logical column
+                // Vec-1-e of the group
                 acc[k] += static_cast<ar_type>(s.a[k][e]) *
                           xv[Upper ? Vec - 1 - e : e];
             }
         }
     };
     if (far_end > 0) {
-        stage even, odd;
-        issue(0, even);
-        index_type cb = 0;
-        for (; cb + 1 < far_end; cb += 2) {
-            issue(cb + 1, odd);
-            consume(cb, even);
-            if (cb + 2 < far_end) {
-                issue(cb + 2, even);
-            }
-            consume(cb + 1, odd);
-        }
-        if (cb < far_end) {
-            consume(cb, even);
-        }
-    }
+        stage ring[Depth];
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        const ar_type total = group_all_reduce<LPR>(
-            acc[k], [](ar_type a, ar_type b) { return a + b; });
-        if (col_group == 0) {
-            const int r = wave_u * RW + k * RPI + row_in_inst;
-            correction[r] = (base + r < n) ? total : ar_type{};
+        for (int d = 0; d < Depth; ++d) {
+            if (d < far_end) {
+                issue(d, ring[d]);
+            }
+        }
+        for (index_type cb0 = 0; cb0 < far_end; cb0 += Depth) {
+#pragma unroll
+            for (int d = 0; d < Depth; ++d) {
+                const index_type cb = cb0 + d;
+                if (cb < far_end) {
+                    consume(cb, ring[d]);
+                    if (cb + Depth < far_end) {
+                        issue(cb + Depth, ring[d]);
+                    }
+                }
+            }
         }
     }
+    ACCBLAS_TRSV_WIDE_STAMP(2);  // this wave consumed its last far panel
+    // this reduction sits between the arrival of x_{b-2} and c, i.e. on the
+    // two-hop path of the chain: NI sums per lane over LPR lanes as a
+    // transposing butterfly on DPP moves (NI x log2(LPR) LDS-crossbar shuffles
+    // took 2 us here, more than a whole hop)
+    {
+        const ar_type total = transpose_reduce_sum<NI, LPR>(acc, lane);
+        if (col_group < NI) {
+            const int r = wave_u * RW + col_group * RPI + row_in_inst;
+            rhs_lds[r] = (base + r < n) ? own_lds[r] - total : ar_type{};
+        }
+    }
+    ACCBLAS_TRSV_WIDE_STAMP(3);  // this wave's far sums reduced
     __syncthreads();
+    ACCBLAS_TRSV_WIDE_STAMP(4);  // every wave's far sums in LDS
 
-    // ---- tail: x_b = inv(T) rhs_far - W x_{b-1} -----------------------------
-    // c = inv(T) rhs_far with rhs_far[k] = own[k] - correction[k]: both vectors
-    // are in LDS for all 128 rows, inv(T) is read from the staging tiles
-    // (this mat-vec is done before the wait; only W needs to be in registers)
-    ar_type sum[4] = {};
-#pragma unroll
-    for (int q = 0; q < CG; ++q) {
-        const int k = group * CG + q;
-        const ar_type rhs_k =
-            (base + k < n) ? own_lds[k] - correction[k] : ar_type{};
-        sum[q & 3] += inv_entry(k) * rhs_k;
+    // the poller's first probe for x_{b-1} travels while c is computed
+    granule_word tail_raw0[io::words];
+    granule_word tail_raw1[io::words];
+    if (block > 0 && wave_u == 0) {
+        poll_begin(base - R + lane, tail_raw0, tail_raw1);
     }
-    if (block > 0) {
-        // critical path: waves 0 and G poll the two halves of x_{b-1}
-        if (group == 0) {
-            granule_word raw[io::words];
-            const index_type prev = base - T + half * H + lane;  // always < n
-            io::load(granules, prev, raw);
-            while (!__all(io::ready(raw)) &&
-                   !detail::spin_expired(spins, helper)) {
-                io::load(granules, prev, raw);
+    // ---- c = inv(T) rhs_far for this lane's row (before the wait) ----------
+    // a row's columns are split over its four lanes (k = fk mod 4)
+    ar_type c_value;
+    {
+        ar_type part[4] = {};
+        for (int k4 = 0; k4 < k_end; k4 += 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k4 + q * 4 + fk;
+                part[q] += inv_entry(own_tile_row, k) * rhs_lds[k];
             }
-            x_prev_lds[half * H + lane] =
-                static_cast<ar_type>(io::decode(raw));
+        }
+        c_value = detail::quad_column_sum((part[0] + part[1]) +
+                                          (part[2] + part[3]));
+    }
+
+    ACCBLAS_TRSV_WIDE_STAMP(5);  // c ready
+    // ---- critical path: x_b = c - W x_{b-1} ---------------------------------
+    ar_type solution_value = c_value;
+    if (block > 0) {
+        if (wave_u == 0) {
+            // ONE wave polls the 128 granules of x_{b-1} (two per lane) and
+            // hands them over through LDS as stored (the lanes widen them),
+            // already in the lanes' read order: element 16 tj + within goes
+            // to lane group quad(within), position 4 tj + reg(within)
+            poll_finish(base - R + lane, tail_raw0, tail_raw1);
+            if (lane == 0) {
+                // blocks 0 .. b-1 are published and visible (just read from
+                // memory): tell the workgroups far behind the front
+                __hip_atomic_fetch_max(&session.state->front,
+                                       static_cast<unsigned int>(block),
+                                       __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int pos =
+                slot::quad(lane & 15) * 32 + (lane >> 4) * 4 + slot::reg(lane & 15);
+            x_perm[pos] = io::decode(tail_raw0);
+            x_perm[pos + 16] = io::decode(tail_raw1);
+            ACCBLAS_TRSV_WIDE_STAMP(6);  // x_{b-1} observed (wave 0 only)
         }
         __syncthreads();
+        ACCBLAS_TRSV_WIDE_STAMP(7);  // x_{b-1} handed over
+        ar_type part[8] = {};
 #pragma unroll
-        for (int q = 0; q < CG; ++q) {
-            sum[q & 3] -= w_reg[q] * x_prev_lds[group * CG + q];
+        for (int tj = 0; tj < R / 16; ++tj) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = tj * 4 + reg;
+                part[i & 7] +=
+                    w_acc[tj][reg] * static_cast<ar_type>(x_perm[fk * 32 + i]);
+            }
+        }
+        const ar_type total = detail::quad_column_sum(
+            ((part[0] + part[1]) + (part[2] + part[3])) +
+            ((part[4] + part[5]) + (part[6] + part[7])));
+        solution_value = c_value - total;
+        ACCBLAS_TRSV_WIDE_STAMP(8);  // mat-vec done
+    }
+    {
+        const index_type own_row = base + own_tile_row;
+        if (fk == 0 && own_row < n) {
+            const st_type solution = static_cast<st_type>(solution_value);
+            io::publish(granules, own_row, solution, epoch);  // hand-off first
+            x_data[phys(own_row) * x_inc] = solution;         // the user's vector
         }
     }
-    part[wave_u * H + lane] = (sum[0] + sum[1]) + (sum[2] + sum[3]);
+    ACCBLAS_TRSV_WIDE_STAMP(9);  // published
+#ifdef ACCBLAS_TRSV_WIDE_DIAG
+    if (lane == 0 && trsv_wide_diag_buffer != nullptr) {
+        for (int i = 0; i < 12; ++i) {
+            trsv_wide_diag_buffer[(block * Waves + wave_u) * 12 + i] =
+                diag_stamp[i];
+        }
+    }
+#endif
+
+    // ---- re-arm the workspace for the next solve (as `kernel::trsv`) -------
+    // (`front` was last raised by this block's poller, long before this block
+    // counts as finished)
     __syncthreads();
-    if (group == 0) {
-        const ar_type *mine = part + half * G * H;
-        const ar_type total = (mine[lane] + mine[H + lane]) +
-                              (mine[2 * H + lane] + mine[3 * H + lane]);
-        const st_type solution = static_cast<st_type>(total);
-        if (own_valid) {
-            io::publish(granules, own_row, solution);  // hand-off first
-            *own_addr = solution;                       // the user's vector
+    if (threadIdx.x == 0) {
+        drain_vmem();  // this thread's raise of `front` has been performed
+        const unsigned int done = __hip_atomic_fetch_add(
+            &session.state->finished, 1u, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+        is_last = done == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last) {
+        std::uint32_t next_epoch = epoch + 1;
+        if (next_epoch == 0) {
+            for (index_type i = threadIdx.x; i < session.capacity_words;
+                 i += blockDim.x) {
+                __hip_atomic_store(granules + i, granule_word{0},
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            next_epoch = trsv_first_epoch;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&session.state->next_ticket, 0u,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&session.state->finished, 0u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&session.state->front, 0u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&session.state->epoch, next_epoch,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -384,60 +676,80 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
 }  // namespace kernel
 
 
-/**
- * Launches the 128-row kernel when the operands allow it (16-byte aligned
- * matrix base and row stride, Upper: n % Vec == 0, storage <= 4 bytes,
- * n >= trsv_wide_min_n); `*launched` tells. The workspace is the same as for
- * `launch_trsv` (one granule entry per element of x).
- */
-template <typename ArType, typename MtxView, typename XView>
-hipError_t try_launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
-                                const XView &x, std::uint32_t *helper,
-                                granule_word *granules, hipStream_t stream,
-                                bool *launched)
+/** Dynamic LDS on top of the static arrays so that ONE workgroup is resident
+ *  per CU (see `trsv_single_block_pad`); fp64 arithmetic needs none (136 KiB
+ *  of static LDS). */
+template <typename ArType>
+constexpr unsigned trsv_wide_single_block_pad()
+{
+    constexpr std::size_t H = trsv_tile;
+    constexpr std::size_t static_bytes =
+        sizeof(ArType) * (4 * H * (H + 1) + 3 * trsv_wide_rows) + 16;
+    constexpr std::size_t needed = 160 * 1024 / 2 + 2048;
+    return static_bytes >= needed
+               ? 0u
+               : static_cast<unsigned>(needed - static_bytes);
+}
+
+
+/** Operands the 128-row kernel takes: 16-byte aligned matrix base and row
+ *  stride, and for upper solves n a multiple of the vector length. */
+template <typename MtxView>
+bool trsv_wide_applicable(bool upper, const MtxView &mtx)
 {
     using mtx_traits = view_traits<MtxView>;
+    using st_type = std::remove_cv_t<typename mtx_traits::storage_type>;
+    constexpr int vec16 = 16 / sizeof(st_type);
+    return is_aligned(mtx_traits::data(mtx), 16) &&
+           mtx_traits::stride(mtx) % vec16 == 0 &&
+           (!upper || mtx.length(0) % vec16 == 0);
+}
+
+
+#ifndef ACCBLAS_TRSV_WIDE_DEPTH
+#define ACCBLAS_TRSV_WIDE_DEPTH 2
+#endif
+
+template <typename ArType, typename MtxView, typename XView>
+hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
+                            const XView &x, std::uint32_t *helper,
+                            const trsv_session &session, hipStream_t stream)
+{
     using st_type =
         std::remove_cv_t<typename view_traits<XView>::storage_type>;
-    *launched = false;
-    if constexpr (sizeof(st_type) > 4) {
+    static_assert(view_traits<MtxView>::is_pointer_view &&
+                      view_traits<XView>::is_pointer_view,
+                  "reduced_row_major / row_major / plain views only");
+    const index_type n = mtx.length(0);
+    if (n <= 0) {
         return hipSuccess;
-    } else {
-        constexpr int vec16 = 16 / sizeof(st_type);
-        const index_type n = mtx.length(0);
-        const bool vec_ok = is_aligned(mtx_traits::data(mtx), 16) &&
-                            mtx_traits::stride(mtx) % vec16 == 0 &&
-                            (!upper || n % vec16 == 0);
-        if (n < trsv_wide_min_n || !vec_ok) {
-            return hipSuccess;
-        }
-        const dim3 grid(static_cast<unsigned>(ceildiv(n, trsv_wide_tile)));
-        const dim3 block(trsv_wide_waves * wave_size);
-        const index_type num_words = n * trsv_granule_words<st_type>();
-        const unsigned init_blocks = static_cast<unsigned>(
-            std::min<index_type>(ceildiv(num_words, 256), 512));
-        kernel::trsv_init<<<init_blocks, 256, 0, stream>>>(helper, granules,
-                                                           num_words);
-        if (upper) {
-            if (unit_diag) {
-                kernel::trsv_wide<true, true, vec16, ArType>
-                    <<<grid, block, 0, stream>>>(mtx, x, helper, granules);
-            } else {
-                kernel::trsv_wide<true, false, vec16, ArType>
-                    <<<grid, block, 0, stream>>>(mtx, x, helper, granules);
-            }
-        } else {
-            if (unit_diag) {
-                kernel::trsv_wide<false, true, vec16, ArType>
-                    <<<grid, block, 0, stream>>>(mtx, x, helper, granules);
-            } else {
-                kernel::trsv_wide<false, false, vec16, ArType>
-                    <<<grid, block, 0, stream>>>(mtx, x, helper, granules);
-            }
-        }
-        *launched = true;
-        return hipGetLastError();
     }
+    constexpr int vec16 = 16 / sizeof(st_type);
+    // a sweep step of 8-byte storage covers 64 columns: 16 load instructions
+    // per lane and step would not leave registers for two steps in flight
+    constexpr int panel_cols = sizeof(st_type) == 8 ? 64 : 128;
+    constexpr int depth = ACCBLAS_TRSV_WIDE_DEPTH;
+    const dim3 grid(static_cast<unsigned>(ceildiv(n, trsv_wide_rows)));
+    const dim3 block(trsv_wide_waves * wave_size);
+    const unsigned pad = trsv_wide_single_block_pad<ArType>();
+#define ACCBLAS_TRSV_WIDE_LAUNCH(_upper, _unit)                                \
+    kernel::trsv_wide<_upper, _unit, vec16, panel_cols, depth, ArType>         \
+        <<<grid, block, pad, stream>>>(mtx, x, helper, session)
+    if (upper) {
+        if (unit_diag) {
+            ACCBLAS_TRSV_WIDE_LAUNCH(true, true);
+        } else {
+            ACCBLAS_TRSV_WIDE_LAUNCH(true, false);
+        }
+    } else {
+        if (unit_diag) {
+            ACCBLAS_TRSV_WIDE_LAUNCH(false, true);
+        } else {
+            ACCBLAS_TRSV_WIDE_LAUNCH(false, false);
+        }
+    }
+#undef ACCBLAS_TRSV_WIDE_LAUNCH
+    return hipGetLastError();
 }
 
 

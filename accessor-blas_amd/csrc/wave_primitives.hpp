@@ -47,6 +47,102 @@ __device__ __forceinline__ T group_all_reduce(T value, Op op)
 }
 
 
+/** DPP controls used below (data-parallel-primitive lane moves run on the
+ *  vector ALU: a few cycles, where a `ds_bpermute` shuffle costs a trip through
+ *  the LDS crossbar). */
+constexpr int dpp_quad_swap_1 = 0xB1;   // quad_perm:[1,0,3,2]: lane ^ 1
+constexpr int dpp_quad_swap_2 = 0x4E;   // quad_perm:[2,3,0,1]: lane ^ 2
+constexpr int dpp_row_rotate_4 = 0x124;  // row_ror:4 inside each 16-lane row
+constexpr int dpp_row_rotate_8 = 0x128;  // row_ror:8
+
+/** `value` of the lane that DPP control `Ctrl` names (4- and 8-byte types). */
+template <int Ctrl, typename T>
+__device__ __forceinline__ T dpp_move(T value)
+{
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4/8-byte values only");
+    int words[sizeof(T) / 4];
+    __builtin_memcpy(words, &value, sizeof(T));
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) {
+        words[i] = __builtin_amdgcn_update_dpp(0, words[i], Ctrl, 0xF, 0xF, true);
+    }
+    T out;
+    __builtin_memcpy(&out, words, sizeof(T));
+    return out;
+}
+
+
+/**
+ * Sums Count values per lane over groups of `Width` consecutive lanes
+ * (Count a power of two <= 16, Width = 16, 32 or 64) in
+ * log2(Width) exchange steps that HALVE the number of values a lane carries
+ * (a transposing butterfly): Count - 1 + log2(Width / Count) lane moves per
+ * lane instead of Count * log2(Width). Exchanges over lane bits 0..3 are DPP
+ * moves (bits 2 and 3 as rotations inside the 16-lane row, which pair every
+ * lane with one whose bit differs), bits 4 and 5 `__shfl_xor`. Every lane of a
+ * group ends with the group's total of value index `lane & (Count - 1)`;
+ * fixed order, so the result is reproducible.
+ */
+template <int Count, int Width, typename T>
+__device__ __forceinline__ T transpose_reduce_sum(const T (&values)[Count],
+                                                  int lane)
+{
+    static_assert(Count >= 1 && (Count & (Count - 1)) == 0 && Count <= 16,
+                  "Count must be a power of two <= 16");
+    static_assert((Width == 16 || Width == 32 || Width == 64) && Count <= Width,
+                  "Width must be 16, 32 or 64 lanes");
+    T cur[Count];
+#pragma unroll
+    for (int i = 0; i < Count; ++i) {
+        cur[i] = values[i];
+    }
+    // from[bit](v) = v of the lane paired with this one across lane bit `bit`
+    const auto from = [](auto bit_tag, T v) -> T {
+        constexpr int bit = decltype(bit_tag)::value;
+        if (bit == 0) {
+            return dpp_move<dpp_quad_swap_1>(v);
+        } else if (bit == 1) {
+            return dpp_move<dpp_quad_swap_2>(v);
+        } else if (bit == 2) {
+            return dpp_move<dpp_row_rotate_4>(v);
+        } else if (bit == 3) {
+            return dpp_move<dpp_row_rotate_8>(v);
+        } else {
+            return __shfl_xor(v, 1 << bit, wave_size);
+        }
+    };
+    constexpr int halving_steps = Count == 1 ? 0 : (Count == 2 ? 1 : (Count == 4 ? 2 : (Count == 8 ? 3 : 4)));
+    constexpr int all_steps = Width == 16 ? 4 : (Width == 32 ? 5 : 6);
+    // halving steps: a lane keeps the values whose index bit equals its own
+    // lane bit and receives the partner's copies of those
+    const auto halve = [&](auto bit_tag, int live) {
+        constexpr int bit = decltype(bit_tag)::value;
+        const bool mine = (lane >> bit) & 1;
+#pragma unroll
+        for (int j = 0; j < Count / 2; ++j) {
+            if (j < live / 2) {
+                const T keep = mine ? cur[2 * j + 1] : cur[2 * j];
+                const T send = mine ? cur[2 * j] : cur[2 * j + 1];
+                cur[j] = keep + from(bit_tag, send);
+            }
+        }
+    };
+    if (halving_steps > 0) halve(std::integral_constant<int, 0>{}, Count);
+    if (halving_steps > 1) halve(std::integral_constant<int, 1>{}, Count / 2);
+    if (halving_steps > 2) halve(std::integral_constant<int, 2>{}, Count / 4);
+    if (halving_steps > 3) halve(std::integral_constant<int, 3>{}, Count / 8);
+    T total = cur[0];
+    // the remaining lane bits: plain all-reduce of the one value left
+    if (halving_steps <= 0 && all_steps > 0) total += from(std::integral_constant<int, 0>{}, total);
+    if (halving_steps <= 1 && all_steps > 1) total += from(std::integral_constant<int, 1>{}, total);
+    if (halving_steps <= 2 && all_steps > 2) total += from(std::integral_constant<int, 2>{}, total);
+    if (halving_steps <= 3 && all_steps > 3) total += from(std::integral_constant<int, 3>{}, total);
+    if (all_steps > 4) total += from(std::integral_constant<int, 4>{}, total);
+    if (all_steps > 5) total += from(std::integral_constant<int, 5>{}, total);
+    return total;
+}
+
+
 /**
  * Sum over the 64 lanes of a wave; the total is valid in lane 0 (other lanes
  * hold partial garbage). Uses shfl_down: offsets 32, 16, 8, 4, 2, 1.

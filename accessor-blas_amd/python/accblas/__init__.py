@@ -81,6 +81,13 @@ SIGNATURES = {
     "accblas_trsv": (_int, [_int, _int, _int, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "accblas_acc_trsv": (_int, [_int, _int, _int, _int, _i64, _vp, _i64, _vp, _i64,
                                 _vp, _vp]),
+    "accblas_trsv_workspace_bytes": (_int, [_int, _i64, ctypes.POINTER(ctypes.c_size_t)]),
+    "accblas_trsv_workspace_init": (_int, [_vp, ctypes.c_size_t, _vp]),
+    "accblas_trsv_ws": (_int, [_int, _int, _int, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
+                               ctypes.c_size_t, _vp]),
+    "accblas_acc_trsv_ws": (_int, [_int, _int, _int, _int, _i64, _vp, _i64, _vp, _i64,
+                                   _vp, _vp, ctypes.c_size_t, _vp]),
+    "accblas_trsv_release_workspace": (_int, [_vp]),
     "accblas_convert": (_int, [_int, _vp, _int, _vp, _i64, _vp]),
 }
 
@@ -267,6 +274,42 @@ def acc_trsv(ar, st, uplo, diag, n, A, lda, x, incx, helper, stream=None):
     """`acc_trsv<ArType, StType>` (`cuda/trsv_kernels.cuh:918-961`)."""
     _check(load().accblas_acc_trsv(ar, st, uplo, diag, n, _ptr(A), lda, _ptr(x), incx,
                                    _ptr(helper), _stream(stream)))
+
+
+def _nbytes(buf):
+    return buf.numel() * buf.element_size() if hasattr(buf, "numel") else 0
+
+
+def trsv_workspace_bytes(st, n):
+    """Bytes of a caller-owned TRSV hand-off workspace (`accblas_trsv_workspace_bytes`)."""
+    out = ctypes.c_size_t()
+    _check(load().accblas_trsv_workspace_bytes(st, n, ctypes.byref(out)))
+    return out.value
+
+
+def trsv_workspace_init(workspace, stream=None):
+    """Zeroes and arms a workspace (a uint8 device tensor) once (`accblas_trsv_workspace_init`)."""
+    _check(load().accblas_trsv_workspace_init(_ptr(workspace), _nbytes(workspace),
+                                              _stream(stream)))
+
+
+def trsv_ws(vt, uplo, diag, n, A, lda, x, incx, helper, workspace, stream=None):
+    """`accblas_trsv_ws`: `trsv<ValueType>` on a caller-owned workspace."""
+    _check(load().accblas_trsv_ws(vt, uplo, diag, n, _ptr(A), lda, _ptr(x), incx,
+                                  _ptr(helper), _ptr(workspace), _nbytes(workspace),
+                                  _stream(stream)))
+
+
+def acc_trsv_ws(ar, st, uplo, diag, n, A, lda, x, incx, helper, workspace, stream=None):
+    """`accblas_acc_trsv_ws`: `acc_trsv<ArType, StType>` on a caller-owned workspace."""
+    _check(load().accblas_acc_trsv_ws(ar, st, uplo, diag, n, _ptr(A), lda, _ptr(x), incx,
+                                      _ptr(helper), _ptr(workspace), _nbytes(workspace),
+                                      _stream(stream)))
+
+
+def trsv_release_workspace(stream=None):
+    """Frees the library-owned workspaces of (current device, stream)."""
+    _check(load().accblas_trsv_release_workspace(_stream(stream)))
 
 
 def convert(dst_t, dst, src_t, src, n, stream=None):

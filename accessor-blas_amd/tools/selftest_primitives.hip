@@ -45,6 +45,12 @@ struct results {
     fixed_point atomic_cas;    // CAS fallback
     double lane_broadcast[64];
     double agent_roundtrip;
+    // transpose_reduce_sum<Count, Width>: one result per lane
+    double transpose_8_32[64];
+    double transpose_4_16[64];
+    double transpose_16_64[64];
+    double transpose_1_64[64];
+    float transpose_2_16[64];
 };
 
 __global__ __launch_bounds__(256) void reductions(results *out)
@@ -80,6 +86,28 @@ __global__ __launch_bounds__(256) void reductions(results *out)
     }
 }
 
+// lane l, value index i carries (i + 1) * 1000 + l (exact in fp32/fp64): the
+// group total of index i is Width * (i + 1) * 1000 + sum of the group's lanes
+template <int Count, int Width, typename T>
+__device__ T transpose_case(int lane)
+{
+    T values[Count];
+    for (int i = 0; i < Count; ++i) {
+        values[i] = T((i + 1) * 1000 + lane);
+    }
+    return transpose_reduce_sum<Count, Width>(values, lane);
+}
+
+__global__ __launch_bounds__(64) void transposes(results *out)
+{
+    const int lane = lane_id();
+    out->transpose_8_32[lane] = transpose_case<8, 32, double>(lane);
+    out->transpose_4_16[lane] = transpose_case<4, 16, double>(lane);
+    out->transpose_16_64[lane] = transpose_case<16, 64, double>(lane);
+    out->transpose_1_64[lane] = transpose_case<1, 64, double>(lane);
+    out->transpose_2_16[lane] = transpose_case<2, 16, float>(lane);
+}
+
 __global__ __launch_bounds__(256) void atomics(results *out)
 {
     atomic_add(&out->atomic_f32, 0.25f);
@@ -102,6 +130,7 @@ int main()
     CHECK(hipMalloc(&dev, sizeof(results)));
     CHECK(hipMemset(dev, 0, sizeof(results)));
     reductions<<<1, 256>>>(dev);
+    transposes<<<1, 64>>>(dev);
     atomics<<<256, 256>>>(dev);
     atomics_cas<<<64, 256>>>(dev);
     CHECK(hipDeviceSynchronize());
@@ -136,6 +165,19 @@ int main()
         expect(host.lane_broadcast[l] == (63 - l) * 1.5, "read_lane");
     }
     expect(host.agent_roundtrip == 6.5, "store_agent/load_agent");
+    const auto transpose_want = [](int count, int width, int lane) {
+        const int index = lane & (count - 1);
+        const int first = lane / width * width;
+        return double(width) * (index + 1) * 1000 + width * first +
+               width * (width - 1) / 2.0;
+    };
+    for (int l = 0; l < 64; ++l) {
+        expect(host.transpose_8_32[l] == transpose_want(8, 32, l), "transpose_reduce_sum<8, 32>");
+        expect(host.transpose_4_16[l] == transpose_want(4, 16, l), "transpose_reduce_sum<4, 16>");
+        expect(host.transpose_16_64[l] == transpose_want(16, 64, l), "transpose_reduce_sum<16, 64>");
+        expect(host.transpose_1_64[l] == transpose_want(1, 64, l), "transpose_reduce_sum<1, 64>");
+        expect(host.transpose_2_16[l] == float(transpose_want(2, 16, l)), "transpose_reduce_sum<2, 16>");
+    }
     if (failures == 0) {
         std::printf("primitives ok\n");
     }

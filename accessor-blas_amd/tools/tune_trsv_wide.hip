@@ -1,0 +1,133 @@
+// Developer tool (not part of the library): times the 128-row TRSV kernel
+// against the 64-row one for Acc<fp64 arithmetic, fp32 storage>, lower / unit,
+// and prints a per-block timeline from in-register stamps.
+// Usage: tune_trsv_wide [n] [rounds]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#define ACCBLAS_TRSV_WIDE_DIAG
+#include "trsv_wide_kernels.hpp"
+
+#define CHECK(call)                                                        \
+    do {                                                                   \
+        hipError_t e = (call);                                             \
+        if (e != hipSuccess) {                                             \
+            std::fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__,         \
+                         hipGetErrorString(e));                            \
+            std::exit(1);                                                  \
+        }                                                                  \
+    } while (0)
+
+using namespace accblas::dev;
+using ar_type = double;
+using st_type = float;
+using accessor = gko::acc::reduced_row_major<2, ar_type, st_type>;
+using range = gko::acc::range<accessor>;
+using c_range = gko::acc::range<accessor::const_accessor>;
+
+__global__ void fill(st_type *p, size_t n, unsigned seed, float scale)
+{
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned h = unsigned(i) * 2654435761u + seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = ((h & 0xffffff) / float(0x800000) - 1.0f) * scale;
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const long n = argc > 1 ? std::atol(argv[1]) : 65536;
+    const int rounds = argc > 2 ? std::atoi(argv[2]) : 5;
+    st_type *A, *x, *x0;
+    std::uint32_t *helper;
+    granule_word *granules;
+    CHECK(hipMalloc(&A, size_t(n) * n * sizeof(st_type)));
+    CHECK(hipMalloc(&x, n * sizeof(st_type)));
+    CHECK(hipMalloc(&x0, n * sizeof(st_type)));
+    CHECK(hipMalloc(&helper, 16));
+    CHECK(hipMalloc(&granules, n * 16));
+    CHECK(hipMemset(granules, 0, n * 16));
+    trsv_state *state;
+    CHECK(hipMalloc(&state, 64));
+    const trsv_state initial{0u, 0u, trsv_first_epoch, 0u};
+    CHECK(hipMemcpy(state, &initial, sizeof(initial), hipMemcpyHostToDevice));
+    const trsv_session session{state, granules, index_type(n) * 2};
+    fill<<<4096, 256>>>(A, size_t(n) * n, 1, 1.0f / std::sqrt(float(n)));
+    fill<<<64, 256>>>(x0, n, 2, 1.0f);
+    using sz = std::array<gko::acc::size_type, 2>;
+    using st = std::array<gko::acc::size_type, 1>;
+    c_range m(sz{{n, n}}, (const st_type *)A, st{{n}});
+    range xv(sz{{n, 1}}, x, st{{1}});
+    const unsigned blocks = unsigned((n + 127) / 128);
+    struct entry { std::string name; std::function<void()> run; };
+    std::vector<entry> entries = {
+        {"rows64", [&]() { CHECK(launch_trsv<ar_type>(false, true, m, xv, helper, session, nullptr, 1)); }},
+        {"rows128", [&]() { CHECK(launch_trsv_wide<ar_type>(false, true, m, xv, helper, session, nullptr)); }},
+    };
+    hipEvent_t start, stop;
+    CHECK(hipEventCreate(&start));
+    CHECK(hipEventCreate(&stop));
+    std::vector<std::vector<float>> times(entries.size());
+    for (int r = -1; r < rounds; ++r) {
+        for (size_t i = 0; i < entries.size(); ++i) {
+            CHECK(hipMemcpy(x, x0, n * sizeof(st_type), hipMemcpyDeviceToDevice));
+            CHECK(hipEventRecord(start, nullptr));
+            entries[i].run();
+            CHECK(hipEventRecord(stop, nullptr));
+            CHECK(hipEventSynchronize(stop));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, start, stop));
+            if (r >= 0) times[i].push_back(ms);
+        }
+    }
+    const double bytes = sizeof(st_type) * (double(n) * (n - 1) / 2 + 2.0 * n);
+    std::printf("n=%ld bytes=%.0f\n", n, bytes);
+    for (size_t i = 0; i < entries.size(); ++i) {
+        auto t = times[i];
+        std::sort(t.begin(), t.end());
+        std::printf("%-10s min %9.1f us med %9.1f us -> %7.1f GB/s  %6.2f us per 64 rows\n",
+                    entries[i].name.c_str(), t.front() * 1e3, t[t.size() / 2] * 1e3,
+                    bytes / (t.front() * 1e-3) / 1e9, t.front() * 1e3 / ((n + 63) / 64));
+    }
+    // timeline of the 128-row kernel (100 MHz stamps -> us since block 0 started)
+    unsigned long long *diag;
+    CHECK(hipMalloc(&diag, size_t(blocks) * 8 * 12 * 8));
+    CHECK(hipMemset(diag, 0, size_t(blocks) * 8 * 12 * 8));
+    CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_wide_diag_buffer), &diag, sizeof(diag)));
+    CHECK(hipMemcpy(x, x0, n * sizeof(st_type), hipMemcpyDeviceToDevice));
+    entries[1].run();
+    CHECK(hipDeviceSynchronize());
+    std::vector<unsigned long long> s(size_t(blocks) * 8 * 12);
+    CHECK(hipMemcpy(s.data(), diag, s.size() * 8, hipMemcpyDeviceToHost));
+    const unsigned long long t0 = s[0];
+    auto us = [&](unsigned b, int w, int slot) {
+        return (double)(long long)(s[(size_t(b) * 8 + w) * 12 + slot] - t0) * 0.01;
+    };
+    std::printf("columns: | at_last_shared(w0, w7) observed |\n");
+    std::printf("block: start  W_ready | w0: far_last reduced | all_far  c_ready(w0,w7) | seen  handed  "
+                "mv_done(w0,w7)  pub(w0,w7) | hop  seen-prev_pub(max)  pub-seen  c_ready-prevprev_pub\n");
+    auto pub = [&](unsigned b) { double m = 0; for (int w = 0; w < 8; ++w) m = std::max(m, us(b, w, 9)); return m; };
+    for (unsigned b : {0u, 1u, 2u, 3u, 10u, 11u, 30u, 31u, 60u, 61u, 100u, 101u, 150u, 151u, 186u, 187u, 250u, 251u, 400u, 401u, 510u, 511u}) {
+        if (b >= blocks) continue;
+        std::printf("%4u: %8.2f %8.2f | %8.2f %8.2f %8.2f | %8.2f %8.2f | %8.2f  %8.2f %8.2f | %8.2f %8.2f  %8.2f %8.2f  %8.2f %8.2f | %5.2f %5.2f %5.2f %6.2f\n",
+                    b, us(b, 0, 0), us(b, 7, 1), us(b, 0, 10), us(b, 7, 10), us(b, 0, 11), us(b, 0, 2), us(b, 0, 3), us(b, 0, 4), us(b, 0, 5), us(b, 7, 5),
+                    b ? us(b, 0, 6) : 0.0, b ? us(b, 0, 7) : 0.0, b ? us(b, 0, 8) : 0.0, b ? us(b, 7, 8) : 0.0,
+                    us(b, 0, 9), us(b, 7, 9),
+                    b ? pub(b) - pub(b - 1) : 0.0, b ? us(b, 0, 6) - pub(b - 1) : 0.0,
+                    b ? pub(b) - us(b, 0, 6) : 0.0, b > 1 ? std::max(us(b, 0, 5), us(b, 7, 5)) - pub(b - 2) : 0.0);
+    }
+    std::uint32_t h[2];
+    CHECK(hipMemcpy(h, helper, 8, hipMemcpyDeviceToHost));
+    std::printf("helper[0]=%08x\n", h[0]);
+    return 0;
+}

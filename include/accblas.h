@@ -74,19 +74,23 @@ int accblas_version(void);
 size_t accblas_dtype_size(accblas_dtype t);
 
 /* Tuning knobs (no counterpart in the reference, whose choices are
- * compile-time constants). Known names:
- *   "trsv_split"  0 (default) = one workgroup per row block streams and
- *                 solves (`kernel::trsv`); 1 = large aligned systems use the
- *                 role-split kernel (persistent streamers + solvers).
- *   "trsv_wide"   0 (default) / 1 = systems with n >= 4096 and 2- or 4-byte
- *                 storage use 128-row blocks (`kernel::trsv_wide`): half as many
- *                 dependent hops, the folded panel held in registers.
+ * compile-time constants). Every knob takes 0, 1 or 2. Known names:
+ *   "trsv_wide"   1 (default) = systems with n >= 4096 whose matrix base and
+ *                 row stride are 16-byte aligned use 128-row blocks
+ *                 (`kernel::trsv_wide`: half as many dependent hops through
+ *                 memory, the folded panel held in registers), everything
+ *                 else 64-row blocks (`kernel::trsv`); 0 = 64-row blocks only;
+ *                 2 = 128-row blocks whenever the operands allow it.
+ *   "trsv_relay"  64-row kernel only: 1 (default) = the far sweep's x goes
+ *                 through a loader wave and LDS where that was measured to pay
+ *                 (fp16 storage, fp32 arithmetic, fp64 storage from n = 17000);
+ *                 0 = never; 2 = always.
  *   "gemv_skew"   1 (default) = GEMV with fp64 arithmetic and a power-of-two
  *                 row pitch (>= 16 KiB) uses the time-skewed sweep (rows of
  *                 a group walk the columns one chunk apart, against channel
  *                 aliasing of power-of-two pitches); 0 = never; 2 = whenever
  *                 the shape allows it.
- * Unknown names return ACCBLAS_ERR_INVALID_ARGUMENT. */
+ * Unknown names and other values return ACCBLAS_ERR_INVALID_ARGUMENT. */
 int accblas_set_option(const char *name, int value);
 
 /* ---- device / runtime (replaces cuda/utils.cuh:80-107, memory.cuh) ------ */
@@ -175,8 +179,23 @@ int accblas_acc_dot(accblas_handle *handle, accblas_dtype ar, accblas_dtype st,
  * replayed from a hipGraph). After the solve helper[0] is 0xffffffff, or
  * 0xdeadbeef if an internal wait gave up (the result is then invalid; it
  * cannot happen on a healthy device), and helper[1] is the number of 64-row
- * blocks. The hand-off workspace between row blocks is owned by the library,
- * one per (device, stream); calls on one stream serialise as usual. */
+ * blocks.
+ *
+ * Hand-off workspace between row blocks (a 4 KiB state header + one or two
+ * 8-byte words per element of x). The reference's launchers have no argument
+ * for it, so the drop-in entry points (accblas_trsv / accblas_acc_trsv) use a
+ * workspace owned by the library, one per (device, stream): it grows on
+ * demand, a buffer that was handed to a launch is only freed by
+ * accblas_trsv_release_workspace(stream) (so graphs that captured a solve stay
+ * valid when a larger solve makes the stream's workspace grow), and growth is
+ * refused during stream capture. Callers that want to own it use the *_ws
+ * entry points: allocate accblas_trsv_workspace_bytes(st, n_max) bytes
+ * (512-byte aligned; accblas_malloc is), initialise them ONCE with
+ * accblas_trsv_workspace_init, and pass the buffer to any number of solves
+ * with n <= n_max and any storage type no wider than `st`. A workspace serves one
+ * solve at a time: solves sharing one must be ordered (same stream or events).
+ * If a solve is ever aborted mid-kernel, re-initialise the workspace (or
+ * release the library-owned one) before using it again. */
 
 /* `trsv<ValueType>` (cuda/trsv_kernels.cuh:455-488 -> kernels :38-42,
  * :69-235, :263-432). */
@@ -189,6 +208,27 @@ int accblas_trsv(accblas_dtype vt, accblas_uplo uplo, accblas_diag diag,
 int accblas_acc_trsv(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
                      accblas_diag diag, int64_t n, const void *A, int64_t lda,
                      void *x, int64_t incx, uint32_t *helper, void *stream);
+
+/* Bytes of hand-off workspace for solves of up to n unknowns stored as `st`. */
+int accblas_trsv_workspace_bytes(accblas_dtype st, int64_t n, size_t *bytes);
+/* Zeroes the workspace and arms its state (asynchronous on `stream`); once
+ * per buffer, not per solve. */
+int accblas_trsv_workspace_init(void *workspace, size_t workspace_bytes,
+                                void *stream);
+/* accblas_trsv / accblas_acc_trsv on a caller-owned workspace. */
+int accblas_trsv_ws(accblas_dtype vt, accblas_uplo uplo, accblas_diag diag,
+                    int64_t n, const void *A, int64_t lda, void *x,
+                    int64_t incx, uint32_t *helper, void *workspace,
+                    size_t workspace_bytes, void *stream);
+int accblas_acc_trsv_ws(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
+                        accblas_diag diag, int64_t n, const void *A,
+                        int64_t lda, void *x, int64_t incx, uint32_t *helper,
+                        void *workspace, size_t workspace_bytes, void *stream);
+/* Synchronises `stream` and frees every library-owned workspace buffer of
+ * (current device, stream), including retired ones. Graphs that captured a
+ * solve through accblas_trsv / accblas_acc_trsv on that stream must not be
+ * replayed afterwards. */
+int accblas_trsv_release_workspace(void *stream);
 
 /* ---- helpers used by the benchmark setup -------------------------------- */
 

@@ -82,7 +82,9 @@ def test_options_are_validated():
     assert lib.accblas_set_option(b"no_such_option", 1) == -2
     assert lib.accblas_set_option(None, 1) == -2
     assert lib.accblas_set_option(b"gemv_skew", 3) == -2
-    for name, default in ((b"gemv_skew", 1), (b"trsv_split", 0), (b"trsv_wide", 0)):
+    assert lib.accblas_set_option(b"trsv_split", 0) == -2  # removed in round 2
+    for name, default in ((b"gemv_skew", 1), (b"trsv_relay", 1), (b"trsv_wide", 1)):
+        assert lib.accblas_set_option(name, 3) == -2
         assert lib.accblas_set_option(name, default) == 0
 
 

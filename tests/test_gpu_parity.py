@@ -282,7 +282,40 @@ def test_acc_dot_result_type_and_strides(gpu, mode):
 
 
 # --------------------------------------------------------------------------- TRSV
+KERNELS = {
+    # name -> (trsv_wide, trsv_relay) of accblas_set_option
+    "rows64": (0, 1),         # 64-row blocks, loader wave by the measured rule
+    "rows64_direct": (0, 0),  # every worker polls the granules it needs
+    "rows64_relay": (0, 2),   # x through the loader wave and LDS, all types/sizes
+    "rows128": (2, 1),        # 128-row blocks wherever the operands allow it
+}
+
+
+@pytest.fixture
+def trsv_kernel(request, gpu):
+    """Selects the TRSV kernel family for one test, restores the defaults after."""
+    _, accblas = gpu
+    wide, relay = KERNELS[request.param]
+    accblas.set_option("trsv_wide", wide)
+    accblas.set_option("trsv_relay", relay)
+    yield request.param
+    accblas.set_option("trsv_wide", 1)
+    accblas.set_option("trsv_relay", 1)
+
+
+_TRIANGULAR_CACHE = {}
+
+
 def triangular_system(n, lda, upper, seed):
+    key = (n, lda, upper, seed)
+    if key not in _TRIANGULAR_CACHE:
+        if len(_TRIANGULAR_CACHE) > 64:
+            _TRIANGULAR_CACHE.clear()
+        _TRIANGULAR_CACHE[key] = _triangular_system(n, lda, upper, seed)
+    return _TRIANGULAR_CACHE[key]
+
+
+def _triangular_system(n, lda, upper, seed):
     """Well-conditioned unit-bounded triangular factor as the reference builds it:
     partial-pivot LU of a U(-1,1) matrix (`cuda/trsv_memory.cuh:131-168`), the
     bounded unit factor placed in the requested triangle, the opposite triangle
@@ -303,15 +336,19 @@ def triangular_system(n, lda, upper, seed):
     return full.reshape(-1)
 
 
-TRSV_SIZES = [(1, 1), (31, 40), (64, 64), (65, 100), (100, 24000 // 8), (1000, 1000),
-              (2050, 2112)]
+TRSV_SIZES = [(1, 1), (31, 40), (64, 64), (65, 100), (100, 24000 // 8), (128, 128),
+              (200, 256), (264, 264), (1000, 1000), (2050, 2112)]
 
 
-@pytest.mark.parametrize("ar,st", [(F64, F64), (F64, F32), (F32, F32), (F64, F16)])
+@pytest.mark.parametrize("trsv_kernel", list(KERNELS), indirect=True)
+@pytest.mark.parametrize("ar,st", PAIRS)
 @pytest.mark.parametrize("upper", [False, True])
 @pytest.mark.parametrize("unit", [False, True])
 @pytest.mark.parametrize("n,lda", TRSV_SIZES)
-def test_acc_trsv_matches_oracle(gpu, ar, st, upper, unit, n, lda):
+def test_acc_trsv_matches_oracle(gpu, trsv_kernel, ar, st, upper, unit, n, lda):
+    """Every kernel family (64-row blocks direct / through the loader wave,
+    128-row blocks; operands a family cannot take fall back to the 64-row
+    scalar path) x every (arithmetic, storage) pair against both oracle levels."""
     torch, accblas = gpu
     A = oracle.convert(triangular_system(n, lda, upper, 30 + n), st)
     b = make_inputs(31, n, st)
@@ -321,6 +358,7 @@ def test_acc_trsv_matches_oracle(gpu, ar, st, upper, unit, n, lda):
     accblas.acc_trsv(ar, st, accblas.UPPER if upper else accblas.LOWER,
                      accblas.UNIT if unit else accblas.NON_UNIT, n, dA, lda, dx, 1, helper)
     torch.cuda.synchronize()
+    assert int(helper[0].item()) & 0xffffffff == 0xffffffff
     got = dx.cpu().numpy()
     err = oracle.rel_error(want.astype(np.float64), got.astype(np.float64))
     # a triangular solve amplifies rounding by the factor's condition number;
@@ -331,9 +369,10 @@ def test_acc_trsv_matches_oracle(gpu, ar, st, upper, unit, n, lda):
     assert err2 <= 100 * out_tolerance(ar, st), (err2, n)
 
 
+@pytest.mark.parametrize("trsv_kernel", ["rows64", "rows128"], indirect=True)
 @pytest.mark.parametrize("vt", [F32, F64])
 @pytest.mark.parametrize("upper", [False, True])
-def test_plain_trsv_equals_accessor_bitwise(gpu, vt, upper):
+def test_plain_trsv_equals_accessor_bitwise(gpu, trsv_kernel, vt, upper):
     torch, accblas = gpu
     n, lda = 1500, 1536
     A = to_dev(torch, oracle.convert(triangular_system(n, lda, upper, 77), vt))
@@ -420,6 +459,123 @@ def test_launches_on_a_side_stream_and_hipgraph_replay(gpu):
     handle.close()
 
 
+def test_hipgraph_replay_survives_workspace_growth(gpu):
+    """A captured solve bakes the library-owned workspace of its stream into the
+    kernel node. A later, larger solve on the same stream makes that workspace
+    grow; the old buffer must stay allocated (retired, not freed), so replaying the
+    graph afterwards still gives the bits of the eager solve."""
+    torch, accblas = gpu
+    n_small, n_big = 512, 9000
+    A_small = to_dev(torch, oracle.convert(triangular_system(n_small, n_small, False, 401), F32))
+    A_big = to_dev(torch, oracle.convert(triangular_system(n_big, n_big, False, 402), F32))
+    b_small = to_dev(torch, make_inputs(403, n_small, F32))
+    b_big = to_dev(torch, make_inputs(404, n_big, F32))
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()  # a fresh stream: its workspace starts small
+    torch.cuda.synchronize()
+    want = b_small.clone()
+    with torch.cuda.stream(side):
+        accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n_small, A_small, n_small,
+                         want, 1, helper, side)
+    side.synchronize()
+    got = b_small.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n_small, A_small, n_small,
+                         got, 1, helper, torch.cuda.current_stream())
+    # growth during capture is refused (it would need hipMalloc + a memset)
+    grown = b_big.clone()
+    probe = torch.cuda.CUDAGraph()
+    with pytest.raises(accblas.AccblasError) as info:
+        with torch.cuda.graph(probe, stream=side):
+            accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n_big, A_big, n_big,
+                             grown, 1, helper, torch.cuda.current_stream())
+    assert info.value.status == -2 and "capture" in str(info.value)
+    torch.cuda.synchronize()
+    # eager, larger solve on the same stream: the workspace grows
+    grown.copy_(b_big)
+    with torch.cuda.stream(side):
+        accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n_big, A_big, n_big, grown,
+                         1, helper, side)
+    side.synchronize()
+    for _ in range(2):
+        got.copy_(b_small)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    assert int(helper[0].item()) & 0xffffffff == 0xffffffff
+    # and the grown workspace serves the small system as well
+    again = b_small.clone()
+    with torch.cuda.stream(side):
+        accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n_small, A_small, n_small,
+                         again, 1, helper, side)
+    side.synchronize()
+    assert torch.equal(again, want)
+    del graph, probe
+    with torch.cuda.stream(side):
+        accblas.trsv_release_workspace(side)
+
+
+@pytest.mark.parametrize("trsv_kernel", ["rows64", "rows128"], indirect=True)
+def test_caller_owned_workspace(gpu, trsv_kernel):
+    """accblas_trsv_workspace_bytes / _init / accblas_acc_trsv_ws: the caller owns
+    the hand-off workspace (as the reference's caller owns `helper`,
+    cuda/trsv_benchmark.cu:98); same bits as the library-owned path, usable for
+    smaller systems and narrower storage, and capturable without a warm-up."""
+    torch, accblas = gpu
+    n, small = 3000, 700
+    size = accblas.trsv_workspace_bytes(F32, n)
+    assert size == 4096 + 8 * n
+    assert accblas.trsv_workspace_bytes(F64, n) == 4096 + 16 * n
+    workspace = torch.empty(size, dtype=torch.uint8, device="cuda")
+    workspace.fill_(0xAB)  # garbage: init must arm it
+    accblas.trsv_workspace_init(workspace)
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for m, st, upper in [(n, F32, False), (small, F32, True), (n, F16, False), (n, F32, False)]:
+        A = to_dev(torch, oracle.convert(triangular_system(m, m, upper, 410 + m), st))
+        b = to_dev(torch, make_inputs(411, m, st))
+        uplo = accblas.UPPER if upper else accblas.LOWER
+        want, got = b.clone(), b.clone()
+        accblas.acc_trsv(F64, st, uplo, accblas.UNIT, m, A, m, want, 1, helper)
+        accblas.acc_trsv_ws(F64, st, uplo, accblas.UNIT, m, A, m, got, 1, helper, workspace)
+        torch.cuda.synchronize()
+        assert int(helper[0].item()) & 0xffffffff == 0xffffffff
+        assert torch.equal(got, want)
+    # plain entry point
+    A = to_dev(torch, oracle.convert(triangular_system(small, small, False, 420), F64))
+    b = to_dev(torch, make_inputs(421, small, F64))
+    want, got = b.clone(), b.clone()
+    accblas.trsv(F64, accblas.LOWER, accblas.NON_UNIT, small, A, small, want, 1, helper)
+    accblas.trsv_ws(F64, accblas.LOWER, accblas.NON_UNIT, small, A, small, got, 1, helper,
+                    workspace)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # too small for the request / missing
+    with pytest.raises(accblas.AccblasError) as info:
+        accblas.acc_trsv_ws(F64, F64, accblas.LOWER, accblas.UNIT, n, A, n, got, 1, helper,
+                            workspace)
+    assert info.value.status == -2
+    with pytest.raises(accblas.AccblasError) as info:
+        accblas.acc_trsv_ws(F64, F32, accblas.LOWER, accblas.UNIT, small, A, small, got, 1,
+                            helper, None)
+    assert info.value.status == -3
+    # captured without any eager solve on that stream
+    side = torch.cuda.Stream()
+    A = to_dev(torch, oracle.convert(triangular_system(small, small, False, 430), F32))
+    b = to_dev(torch, make_inputs(431, small, F32))
+    want, got = b.clone(), b.clone()
+    accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, small, A, small, want, 1, helper)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        accblas.acc_trsv_ws(F64, F32, accblas.LOWER, accblas.UNIT, small, A, small, got, 1,
+                            helper, workspace, torch.cuda.current_stream())
+    got.copy_(b)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
 def test_trsv_concurrent_streams_and_host_threads(gpu):
     """Solves on different streams use different workspaces and may overlap on
     the device; two host threads may drive them at the same time."""
@@ -474,14 +630,14 @@ def test_trsv_workspace_grows_and_helper_reports_no_timeout(gpu):
 
 def test_trsv_workspace_rearms_itself_between_solves(gpu):
     """One launch per solve: granules of earlier (larger, smaller, other storage
-    type) solves and of the opt-in kernels' `trsv_init` protocol stay in the
-    workspace and must never be taken for this solve's; back-to-back launches
+    type, other kernel family) solves stay in the workspace and must never be
+    taken for this solve's; back-to-back launches
     without a host synchronisation in between must each see a re-armed state."""
     torch, accblas = gpu
     helper = torch.zeros(2, dtype=torch.int32, device="cuda")
     plan = [(5000, F32, None), (1300, F32, None), (1300, F64, None), (5000, F16, None),
-            (4224, F32, "trsv_wide"), (4224, F32, None), (4224, F32, "trsv_split"),
-            (4224, F32, None), (70, F32, None), (5000, F32, None)]
+            (4224, F32, ("trsv_wide", 0)), (4224, F32, None), (1300, F32, ("trsv_wide", 2)),
+            (4224, F32, ("trsv_relay", 2)), (70, F32, None), (5000, F32, None)]
     cases = {}
     for n, st, _ in plan:
         if (n, st) not in cases:
@@ -494,13 +650,13 @@ def test_trsv_workspace_rearms_itself_between_solves(gpu):
         dA, b, _ = cases[(n, st)]
         dx = to_dev(torch, b)
         if option:
-            accblas.set_option(option, 1)
+            accblas.set_option(*option)
         try:
             accblas.acc_trsv(F64, st, accblas.LOWER, accblas.UNIT, n, dA, n, dx, 1, helper)
             accblas.acc_trsv(F64, st, accblas.LOWER, accblas.UNIT, n, dA, n, dx, 1, helper)
         finally:
             if option:
-                accblas.set_option(option, 0)
+                accblas.set_option(option[0], 1)
         outputs.append(dx)
     torch.cuda.synchronize()
     assert int(helper[0].item()) & 0xffffffff == 0xffffffff

@@ -87,12 +87,9 @@ def trsv(n, ar, st, upper, unit=True):
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     print(accblas.device_info(0), flush=True)
-    if os.environ.get("ACCBLAS_TRSV_WIDE") == "1":
-        accblas.set_option("trsv_wide", 1)
-        print("trsv_wide = 1", flush=True)
-    if os.environ.get("ACCBLAS_TRSV_SPLIT") == "1":
-        accblas.set_option("trsv_split", 1)
-        print("trsv_split = 1", flush=True)
+    if os.environ.get("ACCBLAS_TRSV_WIDE"):
+        accblas.set_option("trsv_wide", int(os.environ["ACCBLAS_TRSV_WIDE"]))
+        print("trsv_wide =", os.environ["ACCBLAS_TRSV_WIDE"], flush=True)
     if what in ("all", "gemv"):
         gemv(16384, F64, F64, plain=True)
         gemv(16384, F64, F64)
