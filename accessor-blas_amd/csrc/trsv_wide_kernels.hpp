@@ -30,8 +30,9 @@
 //   * inv(T) stays in LDS (three 64 x 64 tiles) for c = inv(T) rhs_far, which
 //     is computed in the same lane layout before the wait;
 //   * far panels: 16 rows per wave, 16-byte loads of the storage type,
-//     `Depth` panels in flight per wave together with their x granules, FMA
-//     in the arithmetic type, one cross-lane reduction at the end.
+//     `Depth` steps in flight per wave, x through LDS (one reader per
+//     workgroup, a chunk of published block columns at a time), FMA in the
+//     arithmetic type, one transposing cross-lane reduction at the end.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -138,15 +139,12 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     // tiles[0] = D00 -> X00, tiles[1] = D11 -> X11 (inverses column-major,
     // tile[c * ld + r]), tiles[2] = D10 (row-major) -> X10 (column-major),
     // tiles[3] = scratch: inversion, Y = D10 X00, panel chunks
-    __shared__ ar_type tiles[4][H * ld];
+    __shared__ __attribute__((aligned(16))) ar_type tiles[4][H * ld];
     __shared__ ar_type own_lds[R];
     __shared__ ar_type rhs_lds[R];   // own - far correction
-    // x_{b-3} / x_{b-2}, handed over by the one poller (two buffers in turn)
-    __shared__ __attribute__((aligned(16))) ar_type x_far[2][R];
     __shared__ __attribute__((aligned(16))) st_type x_perm[R];    // x_{b-1} in the order the lanes read it
     __shared__ std::int32_t shared_block;
     __shared__ std::uint32_t shared_epoch;
-    __shared__ std::uint32_t shared_front;  // newest `trsv_state::front` seen
     __shared__ bool is_last;
 
     const int lane = lane_id();
@@ -168,7 +166,6 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                                          __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
         shared_block = static_cast<std::int32_t>(ticket);
-        shared_front = 0;
         if (ticket == 0) {
             // `trsv_init` (cuda/trsv_kernels.cuh:38-42) folded into the first
             // block, as in `kernel::trsv`
@@ -375,26 +372,46 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     // ---- far sweep: correction = sum_{c < 128 (block-1)} A[block][c] x_c ----
     // Step cb covers columns [cb * PanelCols, (cb + 1) * PanelCols); load
     // instruction k of a wave covers rows wave*RW + k*RPI + lane/LPR and Vec
-    // consecutive (logical) columns starting at (lane % LPR) * Vec.
-    // The waves sweep independently and poll the x granules they need
-    // themselves - except for the last `shared_columns` block columns
-    // (x_{b-4} .. x_{b-2}), published four to two hops before x_b is due:
-    // "x_{b-2} seen -> sums reduced -> c" is a two-hop path of the chain, a
-    // wave's own poll loop notices a publication one to two memory round trips
-    // late, and eight independent pollers made the path as long as the slowest
-    // of eight detections (timeline in profiles/r02_trsv_wide_timeline.txt).
-    // For those columns ONE wave polls and hands x over through LDS (two
-    // buffers in turn, one barrier per column); their matrix data is
-    // prefetched by the same register ring as every other step.
-    constexpr int shared_columns = 3;
-    const index_type far_end = (block - 1) * PPB;   // steps [0, far_end)
-    const index_type shared_begin =                  // steps fed through LDS
-        far_end > shared_columns * PPB ? far_end - shared_columns * PPB : 0;
+    // consecutive (logical) columns starting at (lane % LPR) * Vec. The
+    // matrix data of the next `Depth` steps is always in flight in a register
+    // ring (it does not depend on x).
+    //
+    // x reaches the waves through LDS, a CHUNK of block columns at a time
+    // (tiles[3] is free after the prologue): the workgroup meets at a chunk
+    // boundary (LDS-only barriers: the matrix prefetches stay in flight), the
+    // chunk's x is written to `x_chunk` as stored, and the waves sweep on
+    // independently:
+    //   * catching up (this workgroup started while the chain's front was
+    //     far ahead): `trsv_state::front` tells how many leading blocks are
+    //     published; up to `chunk_columns` of them are fetched by all threads
+    //     at once. One granule read per element and workgroup instead of one
+    //     per element and WAVE, no x registers in the ring (so it can be one
+    //     step deeper: the per-CU streaming rate of the late workgroups of a
+    //     large solve, 30 GB/s with two steps in flight, was what bounded
+    //     n = 65536), and three barriers per `chunk_columns` x 128 columns;
+    //   * at the front (fewer than two published columns left): one block
+    //     column at a time, polled by wave 0 ALONE on the granules themselves
+    //     and handed over through LDS. Eight waves per workgroup polling on
+    //     their own made "x_{b-2} seen -> sums reduced -> c", a two-hop path
+    //     of the chain, as long as the slowest of eight detections, and ~1500
+    //     waves re-reading the newest 1 KB of granules made those cache lines
+    //     a hot spot right where the next block's poller and the publisher's
+    //     write-through have to get through (profiles/r02_trsv_wide_timeline.txt).
+    //     The poller's probe for the next column is issued BEFORE its own
+    //     matrix prefetch (loads return in order).
+    constexpr int chunk_capacity =
+        static_cast<int>(H * ld * sizeof(ar_type) / (R * sizeof(st_type)));
+    constexpr int chunk_columns =
+        chunk_capacity >= 64 ? 64 : (chunk_capacity >= 32 ? 32 : 16);
+    static_assert(chunk_columns <= chunk_capacity, "x chunk must fit tiles[3]");
+    st_type *const x_chunk = reinterpret_cast<st_type *>(tiles[3]);
+    __shared__ std::int32_t chunk_info[2];  // block columns, x already in LDS
+    const index_type far_columns = block - 1;        // block columns [0, b-1)
+    const index_type far_end = far_columns * PPB;    // steps [0, far_end)
     const int row_in_inst = lane / LPR;
     const int col_group = lane % LPR;
     struct stage {
         st_type a[NI][Vec];
-        granule_word xraw[Vec][io::words];
     };
     const st_type *row_ptr[NI];
 #pragma unroll
@@ -415,96 +432,105 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                 s.a[k][e] = v[e];
             }
         }
-        if (cb < shared_begin) {
-#pragma unroll
-            for (int e = 0; e < Vec; ++e) {
-                io::load(granules, first_col + e, s.xraw[e]);
-            }
-        }
     };
     ar_type acc[NI];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         acc[k] = ar_type{};
     }
-    const auto consume = [&](index_type cb, stage &s) {
-        const index_type first_col = cb * PanelCols + col_group * Vec;
-        ar_type xv[Vec];
-        if (cb < shared_begin) {
-            while (true) {
-                bool ok = true;
+    index_type chunk_first = 0;     // first block column of the chunk in LDS
+    index_type chunk_end_step = 0;  // steps below this have their x in LDS
+    bool at_front = false;          // caught up: one column at a time from now on
+    bool probe_pending = false;     // wave 0: probe of the next column under way
+    granule_word probe0[io::words];
+    granule_word probe1[io::words];
+    // wave 0, at the front: first probe of block column `column`
+    const auto begin_probe = [&](index_type column) {
+        if (wave_u == 0 && at_front && !probe_pending) {
+            poll_begin(column * R + lane, probe0, probe1);
+            probe_pending = true;
+        }
+    };
+    // every thread calls this when its next step is `chunk_end_step`
+    const auto next_chunk = [&]() {
+        const index_type column = chunk_end_step / PPB;
+        lds_barrier();  // nobody reads the old chunk any more (the barriers
+                        // here must not drain the matrix prefetches)
+        if (wave_u == 0) {
+            index_type count = 1;
+            if (!at_front) {
+                // published block columns (relaxed: `front` trails the
+                // granules, so what it promises is in memory)
+                const std::uint32_t front = __hip_atomic_load(
+                    &session.state->front, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+                count = static_cast<index_type>(front) - column;
+                count = count < chunk_columns ? count : chunk_columns;
+                count = count < far_columns - column ? count
+                                                     : far_columns - column;
+            }
+            if (count < 2) {
+                // one block column, by this wave alone (two granules per lane)
+                ACCBLAS_TRSV_WIDE_STAMP(10);
+                if (!probe_pending) {
+                    poll_begin(column * R + lane, probe0, probe1);
+                }
+                poll_finish(column * R + lane, probe0, probe1);
+                probe_pending = false;
+                x_chunk[lane] = io::decode(probe0);
+                x_chunk[H + lane] = io::decode(probe1);
+                ACCBLAS_TRSV_WIDE_STAMP(11);
+                count = 1;
+            }
+            if (lane == 0) {
+                chunk_info[0] = static_cast<std::int32_t>(count);
+            }
+        }
+        lds_barrier();
+        const int count = chunk_info[0];
+        if (count > 1) {
+            // all threads fetch the granules of `count` published columns
+            constexpr int batch = 8 / io::words;
+            const int elements = count * R;
+            for (int e0 = 0; e0 < elements; e0 += batch * Waves * wave_size) {
+                granule_word raw[batch][io::words];
 #pragma unroll
-                for (int e = 0; e < Vec; ++e) {
-                    ok = ok && io::ready(s.xraw[e], epoch);
+                for (int j = 0; j < batch; ++j) {
+                    const int e = e0 + j * Waves * wave_size + threadIdx.x;
+                    if (e < elements) {
+                        io::load(granules, column * R + e, raw[j]);
+                    }
                 }
-                if (__all(ok) || detail::spin_expired(spins, helper)) {
-                    break;
-                }
-                // This column is not published yet (this workgroup has caught
-                // up with the chain's front) and it is at least three hops
-                // from being due: wait for ONE word to move on, politely,
-                // instead of re-reading the granules. ~1500 waves re-reading
-                // the newest 1 KB of granules as fast as they could made those
-                // few cache lines a hot spot exactly where the next block's
-                // poller and the publisher's write-through need to get through
-                // (the hop grew from 0.7 us to 1.3-2 us with the number of
-                // resident workgroups).
-                const std::uint32_t wanted =
-                    static_cast<std::uint32_t>(cb / PPB) + 1;
-                while (true) {
-                    std::uint32_t front = __hip_atomic_load(
-                        &shared_front, __ATOMIC_RELAXED,
-                        __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (front < wanted) {
-                        __builtin_amdgcn_s_sleep(8);
-                        front = __hip_atomic_load(&session.state->front,
-                                                  __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
-                        if (lane == 0) {
-                            __hip_atomic_fetch_max(&shared_front, front,
-                                                   __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int j = 0; j < batch; ++j) {
+                    const int e = e0 + j * Waves * wave_size + threadIdx.x;
+                    if (e < elements) {
+                        while (!io::ready(raw[j], epoch) &&
+                               !detail::spin_expired(spins, helper)) {
+                            io::load(granules, column * R + e, raw[j]);
                         }
-                    }
-                    if (front >= wanted ||
-                        detail::spin_expired(spins, helper)) {
-                        break;
+                        x_chunk[e] = io::decode(raw[j]);
                     }
                 }
-#pragma unroll
-                for (int e = 0; e < Vec; ++e) {
-                    io::load(granules, first_col + e, s.xraw[e]);
-                }
             }
-#pragma unroll
-            for (int e = 0; e < Vec; ++e) {
-                xv[e] = static_cast<ar_type>(io::decode(s.xraw[e]));
-            }
+            lds_barrier();
         } else {
-            const index_type column = cb / PPB;  // block column of the step
-            ar_type *x_buffer = x_far[column & 1];
-            if (cb % PPB == 0) {
-                // every wave has consumed all earlier steps when it gets
-                // here; the buffer was last read two columns ago, before the
-                // previous column's barrier
-                ACCBLAS_TRSV_WIDE_STAMP(10);  // at the shared column (last one stays)
-                if (wave_u == 0) {
-                    granule_word raw0[io::words];
-                    granule_word raw1[io::words];
-                    poll_begin(column * R + lane, raw0, raw1);
-                    poll_finish(column * R + lane, raw0, raw1);
-                    x_buffer[lane] = static_cast<ar_type>(io::decode(raw0));
-                    x_buffer[H + lane] = static_cast<ar_type>(io::decode(raw1));
-                    ACCBLAS_TRSV_WIDE_STAMP(11);  // shared column observed
-                }
-                __syncthreads();
-            }
-            const int offset =
-                static_cast<int>(cb % PPB) * PanelCols + col_group * Vec;
+            at_front = true;  // from now on the columns come one at a time
+        }
+        chunk_first = column;
+        chunk_end_step = (column + count) * PPB;
+    };
+    const auto consume = [&](index_type cb, stage &s) {
+        if (cb == chunk_end_step) {
+            next_chunk();
+        }
+        const int offset = static_cast<int>(cb / PPB - chunk_first) * R +
+                           static_cast<int>(cb % PPB) * PanelCols +
+                           col_group * Vec;
+        ar_type xv[Vec];
 #pragma unroll
-            for (int e = 0; e < Vec; ++e) {
-                xv[e] = x_buffer[offset + e];
-            }
+        for (int e = 0; e < Vec; ++e) {
+            xv[e] = static_cast<ar_type>(x_chunk[offset + e]);
         }
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
@@ -515,6 +541,10 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                 acc[k] += static_cast<ar_type>(s.a[k][e]) *
                           xv[Upper ? Vec - 1 - e : e];
             }
+        }
+        // the poller's probe of the next column goes out before its prefetch
+        if (cb + 1 == chunk_end_step && cb + 1 < far_end) {
+            begin_probe((cb + 1) / PPB);
         }
     };
     if (far_end > 0) {
@@ -707,7 +737,7 @@ bool trsv_wide_applicable(bool upper, const MtxView &mtx)
 
 
 #ifndef ACCBLAS_TRSV_WIDE_DEPTH
-#define ACCBLAS_TRSV_WIDE_DEPTH 2
+#define ACCBLAS_TRSV_WIDE_DEPTH 3
 #endif
 
 template <typename ArType, typename MtxView, typename XView>
@@ -728,7 +758,11 @@ hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
     // a sweep step of 8-byte storage covers 64 columns: 16 load instructions
     // per lane and step would not leave registers for two steps in flight
     constexpr int panel_cols = sizeof(st_type) == 8 ? 64 : 128;
-    constexpr int depth = ACCBLAS_TRSV_WIDE_DEPTH;
+    // steps in flight per wave: as many as the 256 registers of a lane hold
+    // next to the folded panel (fp64 on fp64: two)
+    constexpr int depth = (sizeof(st_type) == 8 && sizeof(ArType) == 8)
+                              ? 2
+                              : ACCBLAS_TRSV_WIDE_DEPTH;
     const dim3 grid(static_cast<unsigned>(ceildiv(n, trsv_wide_rows)));
     const dim3 block(trsv_wide_waves * wave_size);
     const unsigned pad = trsv_wide_single_block_pad<ArType>();

@@ -277,6 +277,17 @@ __device__ __forceinline__ T load_agent(const T *addr)
     return value;
 }
 
+/** Workgroup barrier that orders LDS traffic only: waits for this wave's LDS
+ *  operations, then `s_barrier`. `__syncthreads()` also drains the wave's
+ *  outstanding GLOBAL loads (`s_waitcnt vmcnt(0)`), which stalls a software
+ *  pipeline that keeps prefetches in flight across the barrier. Use it where
+ *  the data handed over lives in LDS and nothing read from global memory is
+ *  published by the barrier. */
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 /** Drains this wave's outstanding vector-memory operations. Written as asm
  *  so the compiler cannot drop it in front of a flag/ticket update (guide:
  *  'Compiler hazard'). */
