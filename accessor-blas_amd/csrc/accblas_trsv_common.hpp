@@ -59,10 +59,14 @@ int trsv_wide_option_value();
 /** Option "trsv_relay": 0 never, 1 by the measured rule (default), 2 always. */
 int trsv_relay_option_value();
 
-/** From this size on the 128-row kernel is the faster one
- *  (profiles/r02_trsv_wide_ab.txt). */
+/** From this size on the 128-row kernel is the faster one for 2- and 4-byte
+ *  storage (profiles/r02_trsv_rows64_vs_rows128.txt: equal at n = 4096, 12-20 %
+ *  faster at 8192, 20-50 % at 24000-65536). With 8-byte storage the two are
+ *  within 2 % of each other at every size (the 128-row kernel then has
+ *  registers for two half-width steps in flight only), so the automatic rule
+ *  keeps the 64-row kernel there. */
 #ifndef ACCBLAS_TRSV_WIDE_MIN_N
-#define ACCBLAS_TRSV_WIDE_MIN_N 4096
+#define ACCBLAS_TRSV_WIDE_MIN_N 6144
 #endif
 
 
@@ -102,7 +106,8 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
     const int wide = trsv_wide_option_value();
     const bool use_wide =
         wide != 0 && dev::trsv_wide_applicable(upper, mtx) &&
-        (wide == 2 || n >= ACCBLAS_TRSV_WIDE_MIN_N);
+        (wide == 2 ||
+         (sizeof(st_type) < 8 && n >= ACCBLAS_TRSV_WIDE_MIN_N));
     if (use_wide) {
         return check_hip(
             dev::launch_trsv_wide<ar_type>(upper, unit_diag, mtx, x, helper,

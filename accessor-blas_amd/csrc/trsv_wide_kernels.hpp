@@ -106,10 +106,11 @@ __device__ __forceinline__ T quad_column_sum(T value)
  * one workspace. Vec = elements per 16-byte load (the matrix base and row
  * stride must be 16-byte aligned, for Upper n % Vec == 0). PanelCols = columns
  * a wave sweeps per step (128, or 64 to halve the registers of a stage),
- * Depth = steps in flight per wave.
+ * Depth = steps in flight per wave, DeepDepth = the same while the folded
+ * panel W is not yet computed (long sweeps defer it).
  */
 template <bool Upper, bool UnitDiag, int Vec, int PanelCols, int Depth,
-          typename ArType, typename MtxView, typename XView>
+          int DeepDepth, typename ArType, typename MtxView, typename XView>
 __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     MtxView mtx, XView x, std::uint32_t *helper, trsv_session session)
 {
@@ -305,11 +306,14 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     // lane l ends with W[16w + (l & 15)][16 tj + mma::row(l, reg)] in
     // w_acc[tj][reg]. The panel P passes through tiles[3] in chunks of 32 rows.
     typename mma::acc_type w_acc[R / 16];
+    // Workgroups with a long far sweep ahead of them compute W late (see
+    // `deferred_columns`): during the bulk of the sweep its 64 registers hold
+    // two more steps of matrix prefetch instead.
+    const auto fold_panel = [&]() {
 #pragma unroll
-    for (int tj = 0; tj < R / 16; ++tj) {
-        w_acc[tj] = typename mma::acc_type{};
-    }
-    if (block > 0) {
+        for (int tj = 0; tj < R / 16; ++tj) {
+            w_acc[tj] = typename mma::acc_type{};
+        }
         constexpr int KC = 32;             // panel rows per chunk
         constexpr int per_thread = KC * R / (Waves * wave_size);  // 8
         ar_type *chunk = tiles[3];         // chunk[kl * R + c]
@@ -347,6 +351,19 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                     }
                 }
             }
+        }
+    };
+    // block columns that are swept after W has been computed when W is
+    // deferred (W takes ~10 us; the chain's front must still be far away)
+    constexpr index_type deferred_columns = 48;
+    const bool defer_fold = block - 1 >= 2 * deferred_columns;
+    if (block > 0 && !defer_fold) {
+        fold_panel();
+    }
+    if (block == 0) {
+#pragma unroll
+        for (int tj = 0; tj < R / 16; ++tj) {
+            w_acc[tj] = typename mma::acc_type{};  // never used: no x_{b-1}
         }
     }
 
@@ -547,26 +564,45 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             begin_probe((cb + 1) / PPB);
         }
     };
-    if (far_end > 0) {
-        stage ring[Depth];
+    // steps [begin, end) with `depth_tag` steps of matrix data in flight
+    const auto sweep = [&](auto depth_tag, index_type begin, index_type end) {
+        constexpr int D = decltype(depth_tag)::value;
+        stage ring[D];
 #pragma unroll
-        for (int d = 0; d < Depth; ++d) {
-            if (d < far_end) {
-                issue(d, ring[d]);
+        for (int d = 0; d < D; ++d) {
+            if (begin + d < end) {
+                issue(begin + d, ring[d]);
             }
         }
-        for (index_type cb0 = 0; cb0 < far_end; cb0 += Depth) {
+        for (index_type cb0 = begin; cb0 < end; cb0 += D) {
 #pragma unroll
-            for (int d = 0; d < Depth; ++d) {
+            for (int d = 0; d < D; ++d) {
                 const index_type cb = cb0 + d;
-                if (cb < far_end) {
+                if (cb < end) {
                     consume(cb, ring[d]);
-                    if (cb + Depth < far_end) {
-                        issue(cb + Depth, ring[d]);
+                    if (cb + D < end) {
+                        issue(cb + D, ring[d]);
                     }
                 }
             }
         }
+    };
+    index_type swept = 0;
+    if (defer_fold) {
+        // the bulk of a long sweep, W not yet computed: a deeper ring. The
+        // per-CU streaming rate of the workgroups that start late bounds a
+        // large solve (n = 65536: the last block streams 33 MB on its own)
+        swept = (far_columns - deferred_columns) * PPB;
+        sweep(std::integral_constant<int, DeepDepth>{}, index_type{0}, swept);
+        lds_barrier();  // x_chunk shares tiles[3] with the panel chunks
+        fold_panel();
+        lds_barrier();
+        at_front = false;  // the front moved on meanwhile: catch up in bulk
+        chunk_end_step = swept;
+        probe_pending = false;
+    }
+    if (far_end > swept) {
+        sweep(std::integral_constant<int, Depth>{}, swept, far_end);
     }
     ACCBLAS_TRSV_WIDE_STAMP(2);  // this wave consumed its last far panel
     // this reduction sits between the arrival of x_{b-2} and c, i.e. on the
@@ -763,11 +799,15 @@ hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
     constexpr int depth = (sizeof(st_type) == 8 && sizeof(ArType) == 8)
                               ? 2
                               : ACCBLAS_TRSV_WIDE_DEPTH;
+    // ... and while the folded panel's registers are still free
+    constexpr int deep_depth =
+        depth + ((sizeof(ArType) == 8 && sizeof(st_type) != 4) ? 2 : 1);
     const dim3 grid(static_cast<unsigned>(ceildiv(n, trsv_wide_rows)));
     const dim3 block(trsv_wide_waves * wave_size);
     const unsigned pad = trsv_wide_single_block_pad<ArType>();
 #define ACCBLAS_TRSV_WIDE_LAUNCH(_upper, _unit)                                \
-    kernel::trsv_wide<_upper, _unit, vec16, panel_cols, depth, ArType>         \
+    kernel::trsv_wide<_upper, _unit, vec16, panel_cols, depth, deep_depth,     \
+                      ArType>                                                  \
         <<<grid, block, pad, stream>>>(mtx, x, helper, session)
     if (upper) {
         if (unit_diag) {
