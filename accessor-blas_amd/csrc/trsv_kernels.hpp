@@ -111,7 +111,7 @@ __device__ unsigned long long *trsv_diag_buffer;
  * workspace for its successor, with nothing kept on the host (so a captured
  * launch can be replayed from a hipGraph):
  *   - granules of a solve carry `epoch` in their tag word (0 = never written,
- *     1 = written by a kernel of the `trsv_init` protocol, >= 2 = epochs);
+ *     1 = unused, >= 2 = epochs);
  *   - row blocks are numbered by tickets drawn from `next_ticket`;
  *   - the last workgroup to finish (counted in `finished`) resets both
  *     counters and moves `epoch` on; when the epoch would wrap it zeroes the
@@ -139,27 +139,6 @@ struct trsv_session {
 
 
 namespace kernel {
-
-
-/**
- * `kernel::trsv_init` (`cuda/trsv_kernels.cuh:38-42`) plus the re-arming of the
- * hand-off workspace: helper[0] = ~0 (stays ~0 unless a bounded spin expired,
- * then 0xdeadbeef), helper[1] = next ticket = 0, every granule word = 0
- * (tag 0 = not published).
- */
-static __global__ __launch_bounds__(256) void trsv_init(
-    std::uint32_t *helper, granule_word *granules, index_type num_words)
-{
-    const index_type tid = index_type{blockIdx.x} * blockDim.x + threadIdx.x;
-    if (tid == 0) {
-        helper[0] = ~std::uint32_t{0};
-        helper[1] = 0;
-    }
-    for (index_type i = tid; i < num_words;
-         i += index_type{gridDim.x} * blockDim.x) {
-        granules[i] = 0;
-    }
-}
 
 
 namespace detail {
@@ -279,9 +258,8 @@ template <typename St>
 struct granule_io {
     static constexpr int words = trsv_granule_words<St>();
 
-    /** `tag` marks the granule as published in THIS solve: 1 for kernels
-     *  whose workspace is zeroed by `trsv_init` before every launch, the
-     *  solve's epoch (>= 2) for `kernel::trsv`, which never zeroes. */
+    /** `tag` marks the granule as published in THIS solve: the solve's epoch
+     *  (>= 2; the workspace is never zeroed between solves). */
     __device__ __forceinline__ static void publish(granule_word *granules,
                                                    index_type element, St value,
                                                    std::uint32_t tag = 1)
@@ -877,10 +855,15 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
                           xv[Upper ? Vec - 1 - e : e];
             }
         }
-        // this wave is done with the slot (its LDS reads above were issued
-        // first and LDS serves a wave's operations in order)
-        if (Relay && lane == 0) {
-            sweep_progress[wave] = wanted;
+        // this wave is done with the slot: the release keeps the compiler from
+        // sinking the x_ring reads (or the FMAs that consume them) below the
+        // progress store, after which the loader may overwrite the slot; LDS
+        // serves a wave's operations in order
+        if (Relay) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) {
+                sweep_progress[wave] = wanted;
+            }
         }
     };
     if (!worker) {
@@ -911,6 +894,7 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
                                           need) &&
                                !detail::spin_expired(spins, helper)) {
                         }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
                     while (!__all(io::ready(raw[i], epoch)) &&
                            !detail::spin_expired(spins, helper)) {
@@ -1097,7 +1081,8 @@ constexpr std::size_t trsv_workspace_bytes(index_type n)
  * puts its far sweep on the same SIMDs, LDS and memory pipes as the block
  * that is on the critical chain: measured with two per CU, n = 65536 took
  * 2.65 ms instead of 2.32 ms and fp64 storage at n = 24000 1.82 ms instead of
- * 0.91 ms (profiles/r01_trsv_occupancy.txt).
+ * 0.91 ms (round-1 A/B of the one-block and two-block builds; the log was not
+ * kept, profiles/r01_trsv_relay_ab.txt is from the one-block build).
  */
 template <typename ArType, int Waves, bool Relay>
 constexpr unsigned trsv_single_block_pad()

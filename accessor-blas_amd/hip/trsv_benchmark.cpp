@@ -248,6 +248,17 @@ int run_gpu(const cli_options &opt)
             }
         }
 
+        // a solve whose internal wait gave up leaves 0xdeadbeef in helper[0]
+        // (include/accblas.h): its numbers would be meaningless
+        std::uint32_t helper_words[2] = {0, 0};
+        HIP_CALL(accblas_memcpy_d2h(helper_words, helper, sizeof(helper_words)));
+        if (helper_words[0] == 0xdeadbeefu) {
+            std::cerr << "trsv_benchmark: a solve at " << num_rows
+                      << " rows reported an expired wait (helper[0] = "
+                         "0xdeadbeef)\n";
+            accblas_vendor_destroy(vendor);
+            return 2;
+        }
         std::cout << num_rows;
         for (const auto &value : local_res) {
             std::cout << DELIM << value;
