@@ -200,8 +200,19 @@ int accblas_vendor_getrf(accblas_vendor_handle *handle, int64_t n, void *A,
     if (status != ACCBLAS_OK) {
         return status;
     }
-    if (n <= 0) {
+    if (n < 0 || n > 0x7fffffff || lda > 0x7fffffff) {
+        return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
+                                  "getrf: n and lda must fit rocblas_int");
+    }
+    if (n == 0) {
         return ACCBLAS_OK;
+    }
+    if (A == nullptr) {
+        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER, "getrf: A is NULL");
+    }
+    if (lda < n) {
+        return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
+                                  "getrf: leading dimension smaller than n");
     }
     rocblas_int *pivots = nullptr;
     rocblas_int *dev_info = nullptr;
