@@ -49,13 +49,15 @@ struct dot_config {
 };
 
 /** Production shapes, chosen by measurement on MI355X (tools/tune_dot.hip,
- *  profiles/r01_tune_dot.txt): 512-thread workgroups, 4 load pairs per lane
- *  in flight, 2 workgroups per CU. Streams beyond the Infinity Cache run
- *  faster when each workgroup sweeps one contiguous slice (6.5 vs 6.2 TB/s at
- *  2 x 1 GiB); smaller ones when the whole grid strides together (5.3 vs
- *  5.0 TB/s at 2 x 64 MiB). */
+ *  profiles/r01_tune_dot.txt, profiles/r02_tune_dot.txt): 512-thread
+ *  workgroups. Streams beyond the Infinity Cache run fastest when each
+ *  workgroup sweeps one contiguous slice with ONE workgroup per CU and 8 load
+ *  pairs per lane in flight (256 KB per CU; 2 x 1 GiB fp32: 306 vs 310 us with
+ *  two workgroups of 4 pairs, 1 GiB of fp16: 156 vs 159 us and 3 % better in
+ *  the median); smaller ones when the whole grid strides together with 2
+ *  workgroups per CU and 4 pairs (5.3 vs 5.0 TB/s at 2 x 64 MiB). */
 using dot_stride_config = dot_config<8, 4, 2, false>;
-using dot_contiguous_config = dot_config<8, 4, 2, true>;
+using dot_contiguous_config = dot_config<8, 8, 1, true>;
 constexpr index_type dot_contiguous_min_bytes = index_type{1} << 27;
 struct dot_auto_config {};
 

@@ -122,6 +122,12 @@ void add_all(P &p, std::vector<entry> &e)
     e.push_back(p.template make<dot_config<16, 2, 2, true>>("w16 u2 b2 contig"));
     e.push_back(p.template make<dot_config<8, 8, 2, true>>("w8 u8 b2 contig"));
     e.push_back(p.template make<dot_config<8, 4, 1, true>>("w8 u4 b1 contig"));
+    e.push_back(p.template make<dot_config<8, 8, 1, true>>("w8 u8 b1 contig"));
+    e.push_back(p.template make<dot_config<8, 6, 2, true>>("w8 u6 b2 contig"));
+    e.push_back(p.template make<dot_config<8, 4, 3, true>>("w8 u4 b3 contig"));
+    e.push_back(p.template make<dot_config<16, 4, 1, true>>("w16 u4 b1 contig"));
+    e.push_back(p.template make<dot_config<16, 4, 2, true>>("w16 u4 b2 contig"));
+    e.push_back(p.template make<dot_config<4, 8, 4, true>>("w4 u8 b4 contig"));
     e.push_back(p.template make<dot_config<8, 4, 4, false>>("w8 u4 b4 stride atomic", true));
 }
 
@@ -140,6 +146,14 @@ int main(int argc, char **argv)
     ws.num_cus = prop.multiProcessorCount;
     {
         problem<double, float> p(1L << 28, ws);
+        p.sweep("Acc<f64,f32>", rounds, [&](std::vector<entry> &e) { add_all(p, e); });
+    }
+    {
+        problem<float, _Float16> p(1L << 28, ws);
+        p.sweep("Acc<f32,f16>", rounds, [&](std::vector<entry> &e) { add_all(p, e); });
+    }
+    {
+        problem<double, float> p(1L << 27, ws);
         p.sweep("Acc<f64,f32>", rounds, [&](std::vector<entry> &e) { add_all(p, e); });
     }
     {

@@ -45,7 +45,8 @@ int accblas_vendor_trsv(accblas_vendor_handle *handle, accblas_dtype vt,
                         accblas_uplo uplo, accblas_diag diag, int64_t n,
                         const void *A, int64_t lda, void *x, int64_t incx);
 
-/* In-place partial-pivot LU (rocsolver_dgetrf) of the n x n fp64 device buffer
+/* In-place partial-pivot LU (rocsolver_dgetrf_64: n * lda may exceed 2^31
+ * elements, as it does for n = 65536) of the n x n fp64 device buffer
  * interpreted COLUMN-major with leading dimension lda, pivots discarded, as
  * cuda/trsv_memory.cuh:150-166 does. Unlike the reference, `info` (host int,
  * may be NULL) is returned so the caller can check it. */
