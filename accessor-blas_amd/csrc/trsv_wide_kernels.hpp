@@ -151,7 +151,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     const int lane = lane_id();
     const int wave_u = __builtin_amdgcn_readfirstlane(wave_id());
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
-    unsigned long long diag_stamp[12] = {};
+    unsigned long long diag_stamp[20] = {};
 #endif
     ACCBLAS_TRSV_WIDE_STAMP(0);  // kernel entry
     const int fi = lane & 15;  // MFMA fragment row (A) / column (B, D)
@@ -176,6 +176,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         }
     }
     __syncthreads();
+    ACCBLAS_TRSV_WIDE_STAMP(12);  // ticket drawn
     const index_type block = shared_block;
     const std::uint32_t epoch = shared_epoch;
     const index_type base = block * R;
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         }
     }
     __syncthreads();
+    ACCBLAS_TRSV_WIDE_STAMP(13);  // tiles staged
 
     // ---- invert D00 (even waves) and D11 (odd waves) at the same time -------
     // (the serial 16 x 16 substitutions run on team wave 0 = waves 0 and 1,
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                                         (wave_u / 2) * wave_size + lane, 256);
     }
     __syncthreads();
+    ACCBLAS_TRSV_WIDE_STAMP(14);  // diagonal tiles inverted
 
     // ---- X10 = -X11 (D10 X00): 16 output tiles, two per wave ---------------
     {
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             }
         }
     }
+    ACCBLAS_TRSV_WIDE_STAMP(15);  // X10 written
     // readers of X10 and the next writers of tiles[3] wait at the barriers of
     // the chunk loop below
 
@@ -695,8 +699,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     ACCBLAS_TRSV_WIDE_STAMP(9);  // published
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
     if (lane == 0 && trsv_wide_diag_buffer != nullptr) {
-        for (int i = 0; i < 12; ++i) {
-            trsv_wide_diag_buffer[(block * Waves + wave_u) * 12 + i] =
+        for (int i = 0; i < 20; ++i) {
+            trsv_wide_diag_buffer[(block * Waves + wave_u) * 20 + i] =
                 diag_stamp[i];
         }
     }

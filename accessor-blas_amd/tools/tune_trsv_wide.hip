@@ -101,18 +101,26 @@ int main(int argc, char **argv)
     }
     // timeline of the 128-row kernel (100 MHz stamps -> us since block 0 started)
     unsigned long long *diag;
-    CHECK(hipMalloc(&diag, size_t(blocks) * 8 * 12 * 8));
-    CHECK(hipMemset(diag, 0, size_t(blocks) * 8 * 12 * 8));
+    CHECK(hipMalloc(&diag, size_t(blocks) * 8 * 20 * 8));
+    CHECK(hipMemset(diag, 0, size_t(blocks) * 8 * 20 * 8));
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_wide_diag_buffer), &diag, sizeof(diag)));
     CHECK(hipMemcpy(x, x0, n * sizeof(st_type), hipMemcpyDeviceToDevice));
     entries[1].run();
     CHECK(hipDeviceSynchronize());
-    std::vector<unsigned long long> s(size_t(blocks) * 8 * 12);
+    std::vector<unsigned long long> s(size_t(blocks) * 8 * 20);
     CHECK(hipMemcpy(s.data(), diag, s.size() * 8, hipMemcpyDeviceToHost));
     const unsigned long long t0 = s[0];
     auto us = [&](unsigned b, int w, int slot) {
-        return (double)(long long)(s[(size_t(b) * 8 + w) * 12 + slot] - t0) * 0.01;
+        return (double)(long long)(s[(size_t(b) * 8 + w) * 20 + slot] - t0) * 0.01;
     };
+    for (unsigned b : {0u, 1u, 2u, 100u}) {
+        if (b >= blocks) continue;
+        std::printf("prologue %3u (w0 / w1 / w7): start %.2f | ticket %.2f %.2f %.2f | staged %.2f %.2f %.2f | "
+                    "inverted %.2f %.2f %.2f | X10 %.2f %.2f %.2f | W or sweep start %.2f %.2f %.2f\n",
+                    b, us(b, 0, 0), us(b, 0, 12), us(b, 1, 12), us(b, 7, 12), us(b, 0, 13), us(b, 1, 13),
+                    us(b, 7, 13), us(b, 0, 14), us(b, 1, 14), us(b, 7, 14), us(b, 0, 15), us(b, 1, 15),
+                    us(b, 7, 15), us(b, 0, 1), us(b, 1, 1), us(b, 7, 1));
+    }
     std::printf("columns: | at_last_shared(w0, w7) observed |\n");
     std::printf("block: start  W_ready | w0: far_last reduced | all_far  c_ready(w0,w7) | seen  handed  "
                 "mv_done(w0,w7)  pub(w0,w7) | hop  seen-prev_pub(max)  pub-seen  c_ready-prevprev_pub\n");
