@@ -19,7 +19,10 @@ def mean_counter(directory, counter, needle):
     vals = []
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] == counter and needle in r["Kernel_Name"]:
+            # `needle` may list alternatives with '|' (kernels with _Float16
+            # operands stay mangled in the rocprofv3 output)
+            if r["Counter_Name"] == counter and any(
+                    part in r["Kernel_Name"] for part in needle.split("|")):
                 vals.append(float(r["Counter_Value"]))
     # the first launch of a case is the warm-up; all launches do the same work
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
