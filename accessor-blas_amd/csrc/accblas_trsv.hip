@@ -14,16 +14,52 @@
 namespace {
 std::atomic<int> trsv_wide_option{1};
 std::atomic<int> trsv_relay_option{1};
+std::atomic<int> trsv_split_from_option{0};
 std::atomic<int> gemv_skew_option_store{1};
 }
 
 int accblas::gemv_skew_option_value() { return gemv_skew_option_store.load(); }
 int accblas::trsv_wide_option_value() { return trsv_wide_option.load(); }
 int accblas::trsv_relay_option_value() { return trsv_relay_option.load(); }
+int accblas::trsv_split_from_option_value()
+{
+    return trsv_split_from_option.load();
+}
+
+int accblas::trsv_num_cus()
+{
+    // per device: a process may drive several
+    static std::mutex guard;
+    static std::map<int, int> cached;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) {
+        return 1;
+    }
+    std::lock_guard<std::mutex> lock(guard);
+    auto found = cached.find(device);
+    if (found == cached.end()) {
+        int count = 0;
+        if (hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount,
+                                  device) != hipSuccess ||
+            count <= 0) {
+            count = 1;
+        }
+        found = cached.emplace(device, count).first;
+    }
+    return found->second;
+}
 
 extern "C" int accblas_set_option(const char *name, int value)
 {
     const std::string key = name != nullptr ? name : "";
+    if (key == "trsv_wide_split_from") {
+        if (value < 0) {
+            return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
+                                      "trsv_wide_split_from takes a count >= 0");
+        }
+        trsv_split_from_option.store(value);
+        return ACCBLAS_OK;
+    }
     std::atomic<int> *target = nullptr;
     if (key == "trsv_wide") {
         target = &trsv_wide_option;

@@ -1066,11 +1066,17 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
 }  // namespace kernel
 
 
-/** Bytes of hand-off workspace `launch_trsv` needs for an n-element solve. */
+/** Bytes of hand-off workspace a solve of n unknowns needs behind the state
+ *  header: one or two granule words per element of x, then (128-row kernel,
+ *  split row blocks) the partial-sum area: 7 x 128 two-word slots per 128-row
+ *  block, 64-word aligned. */
 template <typename St>
 constexpr std::size_t trsv_workspace_bytes(index_type n)
 {
-    return static_cast<std::size_t>(n) * trsv_granule_words<St>() *
+    const index_type x_words =
+        ceildiv(n * trsv_granule_words<St>(), index_type{64}) * 64;
+    const index_type partial_words = ceildiv(n, index_type{128}) * 7 * 128 * 2;
+    return static_cast<std::size_t>(x_words + partial_words) *
            sizeof(granule_word);
 }
 

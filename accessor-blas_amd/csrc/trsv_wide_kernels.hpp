@@ -47,6 +47,39 @@ namespace dev {
 constexpr int trsv_wide_rows = 128;
 constexpr int trsv_wide_waves = 8;
 
+/** Row blocks from `first_block` on are worked on by `parts` workgroups each
+ *  (see `kernel::trsv_wide`); parts == 1 switches the splitting off. */
+/** Block columns next to its diagonal that a workgroup with a long far sweep
+ *  keeps for after the panel fold (see `defer_fold` in the kernel). */
+#ifndef ACCBLAS_TRSV_WIDE_DEFERRED
+#define ACCBLAS_TRSV_WIDE_DEFERRED 48
+#endif
+constexpr index_type trsv_wide_deferred_columns = ACCBLAS_TRSV_WIDE_DEFERRED;
+
+struct trsv_wide_split {
+    int first_block;
+    int parts;
+    int tail_block;  // blocks from here on have `tail_parts` workgroups each
+    int tail_parts;  // (smaller shares: the last tickets run almost alone)
+};
+constexpr int trsv_wide_max_parts = 8;
+
+/** Granule words of the partial-sum area that follows the x granules in the
+ *  workspace: (parts - 1) x 128 partial sums per row block, one or two words
+ *  each (arithmetic type), tagged like the x granules. Sized for fp64
+ *  arithmetic and the maximum number of parts. */
+constexpr index_type trsv_wide_partial_words(index_type n)
+{
+    return ceildiv(n, index_type{trsv_wide_rows}) * (trsv_wide_max_parts - 1) *
+           trsv_wide_rows * 2;
+}
+
+/** First word of that area (64-word aligned behind n x words_per_element). */
+constexpr index_type trsv_wide_partial_offset(index_type n, int words_per_element)
+{
+    return ceildiv(n * words_per_element, index_type{64}) * 64;
+}
+
 
 // Diagnostic builds only (tools/tune_trsv_wide.hip defines
 // ACCBLAS_TRSV_WIDE_DIAG): every wave keeps 100 MHz wall-clock stamps of its
@@ -112,7 +145,8 @@ __device__ __forceinline__ T quad_column_sum(T value)
 template <bool Upper, bool UnitDiag, int Vec, int PanelCols, int Depth,
           int DeepDepth, typename ArType, typename MtxView, typename XView>
 __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
-    MtxView mtx, XView x, std::uint32_t *helper, trsv_session session)
+    MtxView mtx, XView x, std::uint32_t *helper, trsv_session session,
+    trsv_wide_split split)
 {
     using ar_type = decltype(mtx(0, 0) * x(0, 0));
     static_assert(std::is_same<ArType, ar_type>::value,
@@ -121,6 +155,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     using x_traits = view_traits<XView>;
     using st_type = std::remove_cv_t<typename x_traits::storage_type>;
     using io = detail::granule_io<st_type>;
+    using io_ar = detail::granule_io<ar_type>;  // partial sums of split blocks
     using mma = detail::mma_16x16x4<ar_type>;
     using slot = detail::mma_slot<ar_type>;
     constexpr int R = trsv_wide_rows;    // rows per block
@@ -145,6 +180,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     __shared__ ar_type rhs_lds[R];   // own - far correction
     __shared__ __attribute__((aligned(16))) st_type x_perm[R];    // x_{b-1} in the order the lanes read it
     __shared__ std::int32_t shared_block;
+    __shared__ std::int32_t shared_part;  // part of the block, parts - 1 = owner
     __shared__ std::uint32_t shared_epoch;
     __shared__ bool is_last;
 
@@ -166,7 +202,26 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         shared_epoch = __hip_atomic_load(&session.state->epoch,
                                          __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
-        shared_block = static_cast<std::int32_t>(ticket);
+        // tickets -> (row block, part): blocks below split.first_block have one
+        // workgroup; each later block has `parts`, its helpers first and its
+        // owner last, so everything a workgroup waits for has a lower ticket
+        std::int32_t ticket_block = static_cast<std::int32_t>(ticket);
+        std::int32_t ticket_part = 0;
+        if (split.parts > 1 && ticket_block >= split.first_block) {
+            const std::int32_t beyond = ticket_block - split.first_block;
+            const std::int32_t body =
+                (split.tail_block - split.first_block) * split.parts;
+            if (beyond < body) {
+                ticket_block = split.first_block + beyond / split.parts;
+                ticket_part = beyond % split.parts;
+            } else {
+                ticket_block =
+                    split.tail_block + (beyond - body) / split.tail_parts;
+                ticket_part = (beyond - body) % split.tail_parts;
+            }
+        }
+        shared_block = ticket_block;
+        shared_part = ticket_part;
         if (ticket == 0) {
             // `trsv_init` (cuda/trsv_kernels.cuh:38-42) folded into the first
             // block, as in `kernel::trsv`
@@ -181,8 +236,28 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     const std::uint32_t epoch = shared_epoch;
     const index_type base = block * R;
     if (base >= n) {
-        return;  // cannot happen: the grid has exactly ceil(n / R) blocks
+        return;  // cannot happen: the grid covers exactly ceil(n / R) blocks
     }
+    // Split row blocks. A solve with more row blocks than CUs ends with the
+    // blocks that have the MOST far columns starting LAST (when a CU frees up),
+    // each streaming tens of MB alone while more and more CUs idle: at
+    // n = 65536 the second half of the solve ran at 5.1 TB/s against 6.2 TB/s
+    // for the first. From `split.first_block` on a block's far columns
+    // [0, b - 1 - deferred_columns) are divided evenly over parts - 1 helper
+    // workgroups; `parts` consecutive tickets belong to one block: the
+    // helpers first - they only sweep their share, published long before they
+    // start, and hand their 128 partial sums over as tagged granules - and
+    // the owner last: prologue, panel fold, the helpers' sums added in part
+    // order (fixed: the result does not depend on timing), the last
+    // `deferred_columns` block columns and the tail as usual.
+    const int parts_here =
+        (split.parts > 1 && block >= split.first_block)
+            ? (block >= split.tail_block ? split.tail_parts : split.parts)
+            : 1;
+    const int part = shared_part;
+    const bool helper_part = part < parts_here - 1;
+    granule_word *const partials =
+        granules + trsv_wide_partial_offset(n, io::words);
     const auto phys = [n](index_type logical) {
         return Upper ? n - 1 - logical : logical;
     };
@@ -196,14 +271,14 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     const index_type x_inc = x_traits::stride(x);
 
     // this block's right-hand side (never written by another workgroup)
-    if (threadIdx.x < R) {
+    if (!helper_part && threadIdx.x < R) {
         const index_type row = base + threadIdx.x;
         own_lds[threadIdx.x] = row < n ? ar_type(x_data[phys(row) * x_inc])
                                        : ar_type{};
     }
 
     // ---- stage D00, D11, D10 (a wave reads one tile row per load) ----------
-    {
+    if (!helper_part) {
         constexpr int RS = H / Waves;  // tile rows a wave stages
         ar_type d00[RS], d11[RS], d10[RS];
 #pragma unroll
@@ -233,7 +308,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     // ---- invert D00 (even waves) and D11 (odd waves) at the same time -------
     // (the serial 16 x 16 substitutions run on team wave 0 = waves 0 and 1,
     // which sit on different SIMDs)
-    {
+    if (!helper_part) {
         const int team = wave_u % 2;
         ar_type *scratch = tiles[3] + team * 1024;
         detail::invert_tile64<UnitDiag>(tiles[team], scratch, scratch + 512,
@@ -244,7 +319,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     ACCBLAS_TRSV_WIDE_STAMP(14);  // diagonal tiles inverted
 
     // ---- X10 = -X11 (D10 X00): 16 output tiles, two per wave ---------------
-    {
+    if (!helper_part) {
         const int tj = wave_u % 4;
         const int ti_of[2] = {wave_u / 4, 3 - wave_u / 4};
         typename mma::acc_type y[2];
@@ -359,9 +434,9 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     };
     // block columns that are swept after W has been computed when W is
     // deferred (W takes ~10 us; the chain's front must still be far away)
-    constexpr index_type deferred_columns = 48;
+    constexpr index_type deferred_columns = trsv_wide_deferred_columns;
     const bool defer_fold = block - 1 >= 2 * deferred_columns;
-    if (block > 0 && !defer_fold) {
+    if (block > 0 && !defer_fold && !helper_part) {
         fold_panel();
     }
     if (block == 0) {
@@ -427,8 +502,28 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     static_assert(chunk_columns <= chunk_capacity, "x chunk must fit tiles[3]");
     st_type *const x_chunk = reinterpret_cast<st_type *>(tiles[3]);
     __shared__ std::int32_t chunk_info[2];  // block columns, x already in LDS
-    const index_type far_columns = block - 1;        // block columns [0, b-1)
-    const index_type far_end = far_columns * PPB;    // steps [0, far_end)
+    // block columns this workgroup sweeps: [first_column, far_columns). An
+    // unsplit block (or block 0 / 1): [0, b - 1). A split block: its bulk
+    // columns [0, b - 1 - deferred_columns) in `parts_here` equal shares, the
+    // owner's share running on to b - 1.
+    const index_type split_columns =
+        parts_here > 1 ? block - 1 - deferred_columns : index_type{0};
+    // (the owner takes no share of the bulk columns: it starts no earlier
+    // than its helpers, and what it has to do in sequence - prologue, fold,
+    // the last `deferred_columns`, the tail - is what the chain ends up
+    // waiting for at the end of a large solve)
+    const index_type share =
+        parts_here > 1 ? ceildiv(split_columns, index_type{parts_here - 1})
+                       : index_type{0};
+    const index_type first_column =
+        parts_here > 1 ? (share * part < split_columns ? share * part
+                                                       : split_columns)
+                       : index_type{0};
+    const index_type far_columns =
+        helper_part ? (share * (part + 1) < split_columns ? share * (part + 1)
+                                                          : split_columns)
+                    : block - 1;
+    const index_type far_end = far_columns * PPB;    // steps below far_end
     const int row_in_inst = lane / LPR;
     const int col_group = lane % LPR;
     struct stage {
@@ -591,15 +686,60 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             }
         }
     };
-    index_type swept = 0;
+    index_type swept = first_column * PPB;
+    chunk_end_step = swept;
+    if (helper_part) {
+        // a helper's share: bulk columns, nothing else; its 128 sums go to
+        // the owner as tagged granules (this path must not run into the
+        // owner's code below: the compiler would keep the owner's registers
+        // alive across the helper's deep ring)
+        sweep(std::integral_constant<int, DeepDepth>{}, swept, far_end);
+        const ar_type total = transpose_reduce_sum<NI, LPR>(acc, lane);
+        if (col_group < NI) {
+            const int r = wave_u * RW + col_group * RPI + row_in_inst;
+            io_ar::publish(partials,
+                           (block * (trsv_wide_max_parts - 1) + part) * R + r,
+                           total, epoch);
+        }
+    } else {
     if (defer_fold) {
         // the bulk of a long sweep, W not yet computed: a deeper ring. The
         // per-CU streaming rate of the workgroups that start late bounds a
         // large solve (n = 65536: the last block streams 33 MB on its own)
-        swept = (far_columns - deferred_columns) * PPB;
-        sweep(std::integral_constant<int, DeepDepth>{}, index_type{0}, swept);
+        const index_type bulk_end = (block - 1 - deferred_columns) * PPB;
+        if (bulk_end > swept) {
+            sweep(std::integral_constant<int, DeepDepth>{}, swept, bulk_end);
+            swept = bulk_end;
+        }
         lds_barrier();  // x_chunk shares tiles[3] with the panel chunks
         fold_panel();
+        if (parts_here > 1 && threadIdx.x < R) {
+            // the helpers' partial sums, added in part order: they are
+            // subtracted from this row's right-hand side before the sums of
+            // this workgroup's own share (a fixed order, whatever the timing)
+            const index_type slot0 =
+                (block * (trsv_wide_max_parts - 1)) * R + threadIdx.x;
+            granule_word raw[trsv_wide_max_parts - 1][io_ar::words];
+#pragma unroll
+            for (int p = 0; p < trsv_wide_max_parts - 1; ++p) {
+                if (p < parts_here - 1) {
+                    io_ar::load(partials, slot0 + p * R, raw[p]);
+                }
+            }
+            ar_type helped{};
+#pragma unroll
+            for (int p = 0; p < trsv_wide_max_parts - 1; ++p) {
+                if (p < parts_here - 1) {
+                    while (!io_ar::ready(raw[p], epoch) &&
+                           !detail::spin_expired(spins, helper)) {
+                        __builtin_amdgcn_s_sleep(4);
+                        io_ar::load(partials, slot0 + p * R, raw[p]);
+                    }
+                    helped += io_ar::decode(raw[p]);
+                }
+            }
+            own_lds[threadIdx.x] -= helped;
+        }
         lds_barrier();
         at_front = false;  // the front moved on meanwhile: catch up in bulk
         chunk_end_step = swept;
@@ -697,6 +837,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         }
     }
     ACCBLAS_TRSV_WIDE_STAMP(9);  // published
+    }  // owner
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
     if (lane == 0 && trsv_wide_diag_buffer != nullptr) {
         for (int i = 0; i < 20; ++i) {
@@ -776,20 +917,65 @@ bool trsv_wide_applicable(bool upper, const MtxView &mtx)
 }
 
 
-#ifndef ACCBLAS_TRSV_WIDE_DEPTH
-#define ACCBLAS_TRSV_WIDE_DEPTH 3
+#ifndef ACCBLAS_TRSV_WIDE_PARTS
+#define ACCBLAS_TRSV_WIDE_PARTS 5
 #endif
+#ifndef ACCBLAS_TRSV_WIDE_TAIL_PARTS
+#define ACCBLAS_TRSV_WIDE_TAIL_PARTS 8
+#endif
+#ifndef ACCBLAS_TRSV_WIDE_TAIL_BLOCKS
+#define ACCBLAS_TRSV_WIDE_TAIL_BLOCKS 64
+#endif
+
+/** How a solve of n unknowns is split on a device with `num_cus` CUs: row
+ *  blocks that cannot be resident from the start (more blocks than CUs) get
+ *  ACCBLAS_TRSV_WIDE_PARTS workgroups each (4 helpers + the owner), the last
+ *  ACCBLAS_TRSV_WIDE_TAIL_BLOCKS of them ACCBLAS_TRSV_WIDE_TAIL_PARTS: the
+ *  workgroups with the last tickets run almost alone, so their shares decide
+ *  how long the solve's tail is. Measured (profiles/r02_trsv_split_ab.txt,
+ *  us, unsplit -> 5 parts -> 5 parts + 8 for the last 64 blocks):
+ *  n = 40000: 845-863 -> 747-785 -> 748-778; n = 65536: 1554 -> 1563-1608 ->
+ *  1496-1500. */
+inline trsv_wide_split trsv_wide_split_for(index_type n, int num_cus)
+{
+    const int blocks = static_cast<int>(ceildiv(n, index_type{trsv_wide_rows}));
+    // a split block must defer its fold (2 x deferred + 1 far columns at least)
+    constexpr int min_first = 2 * static_cast<int>(trsv_wide_deferred_columns) + 2;
+    const int first = num_cus > min_first ? num_cus : min_first;
+    if (ACCBLAS_TRSV_WIDE_PARTS > 1 && blocks > first) {
+        const int tail_blocks = ACCBLAS_TRSV_WIDE_TAIL_BLOCKS < blocks - first
+                                    ? ACCBLAS_TRSV_WIDE_TAIL_BLOCKS
+                                    : blocks - first;
+        return trsv_wide_split{first, ACCBLAS_TRSV_WIDE_PARTS,
+                               blocks - tail_blocks,
+                               ACCBLAS_TRSV_WIDE_TAIL_PARTS};
+    }
+    return trsv_wide_split{blocks, 1, blocks, 1};
+}
+
+/** Workgroups a solve launches under `split`. */
+inline unsigned trsv_wide_grid(index_type n, const trsv_wide_split &split)
+{
+    const index_type blocks = ceildiv(n, index_type{trsv_wide_rows});
+    return static_cast<unsigned>(
+        split.first_block + (split.tail_block - split.first_block) * split.parts +
+        (blocks - split.tail_block) * split.tail_parts);
+}
 
 template <typename ArType, typename MtxView, typename XView>
 hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
                             const XView &x, std::uint32_t *helper,
-                            const trsv_session &session, hipStream_t stream)
+                            const trsv_session &session, hipStream_t stream,
+                            int num_cus)
 {
     using st_type =
         std::remove_cv_t<typename view_traits<XView>::storage_type>;
     static_assert(view_traits<MtxView>::is_pointer_view &&
                       view_traits<XView>::is_pointer_view,
                   "reduced_row_major / row_major / plain views only");
+    static_assert(ACCBLAS_TRSV_WIDE_PARTS <= trsv_wide_max_parts &&
+                      ACCBLAS_TRSV_WIDE_TAIL_PARTS <= trsv_wide_max_parts,
+                  "too many parts");
     const index_type n = mtx.length(0);
     if (n <= 0) {
         return hipSuccess;
@@ -798,21 +984,22 @@ hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
     // a sweep step of 8-byte storage covers 64 columns: 16 load instructions
     // per lane and step would not leave registers for two steps in flight
     constexpr int panel_cols = sizeof(st_type) == 8 ? 64 : 128;
-    // steps in flight per wave: as many as the 256 registers of a lane hold
-    // next to the folded panel (fp64 on fp64: two)
-    constexpr int depth = (sizeof(st_type) == 8 && sizeof(ArType) == 8)
-                              ? 2
-                              : ACCBLAS_TRSV_WIDE_DEPTH;
-    // ... and while the folded panel's registers are still free
-    constexpr int deep_depth =
-        depth + ((sizeof(ArType) == 8 && sizeof(st_type) != 4) ? 2 : 1);
-    const dim3 grid(static_cast<unsigned>(ceildiv(n, trsv_wide_rows)));
+    // Steps of matrix data in flight per wave. While the folded panel W (64
+    // registers with fp64 arithmetic) is live, a workgroup is at the chain's
+    // front or within 48 columns of its own diagonal - it gets one column per
+    // hop, two steps are plenty - and that is also what the 256 registers of
+    // a lane hold next to W. The bulk of a long sweep runs before W exists
+    // (`defer_fold`, helpers of split blocks): as deep as the registers allow.
+    constexpr int depth = sizeof(st_type) == 2 ? 3 : 2;
+    constexpr int deep_depth = sizeof(st_type) == 2 ? 5 : 4;
+    const trsv_wide_split split = trsv_wide_split_for(n, num_cus);
+    const dim3 grid(trsv_wide_grid(n, split));
     const dim3 block(trsv_wide_waves * wave_size);
     const unsigned pad = trsv_wide_single_block_pad<ArType>();
 #define ACCBLAS_TRSV_WIDE_LAUNCH(_upper, _unit)                                \
     kernel::trsv_wide<_upper, _unit, vec16, panel_cols, depth, deep_depth,     \
                       ArType>                                                  \
-        <<<grid, block, pad, stream>>>(mtx, x, helper, session)
+        <<<grid, block, pad, stream>>>(mtx, x, helper, session, split)
     if (upper) {
         if (unit_diag) {
             ACCBLAS_TRSV_WIDE_LAUNCH(true, true);

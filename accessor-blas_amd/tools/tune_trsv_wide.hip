@@ -55,13 +55,14 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&x, n * sizeof(st_type)));
     CHECK(hipMalloc(&x0, n * sizeof(st_type)));
     CHECK(hipMalloc(&helper, 16));
-    CHECK(hipMalloc(&granules, n * 16));
-    CHECK(hipMemset(granules, 0, n * 16));
+    const size_t ws_bytes = trsv_workspace_bytes<double>(n);
+    CHECK(hipMalloc(&granules, ws_bytes));
+    CHECK(hipMemset(granules, 0, ws_bytes));
     trsv_state *state;
     CHECK(hipMalloc(&state, 64));
     const trsv_state initial{0u, 0u, trsv_first_epoch, 0u};
     CHECK(hipMemcpy(state, &initial, sizeof(initial), hipMemcpyHostToDevice));
-    const trsv_session session{state, granules, index_type(n) * 2};
+    const trsv_session session{state, granules, index_type(ws_bytes / 8)};
     fill<<<4096, 256>>>(A, size_t(n) * n, 1, 1.0f / std::sqrt(float(n)));
     fill<<<64, 256>>>(x0, n, 2, 1.0f);
     using sz = std::array<gko::acc::size_type, 2>;
@@ -72,7 +73,7 @@ int main(int argc, char **argv)
     struct entry { std::string name; std::function<void()> run; };
     std::vector<entry> entries = {
         {"rows64", [&]() { CHECK(launch_trsv<ar_type>(false, true, m, xv, helper, session, nullptr, 1)); }},
-        {"rows128", [&]() { CHECK(launch_trsv_wide<ar_type>(false, true, m, xv, helper, session, nullptr)); }},
+        {"rows128", [&]() { CHECK(launch_trsv_wide<ar_type>(false, true, m, xv, helper, session, nullptr, 256)); }},
     };
     hipEvent_t start, stop;
     CHECK(hipEventCreate(&start));

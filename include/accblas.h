@@ -74,7 +74,8 @@ int accblas_version(void);
 size_t accblas_dtype_size(accblas_dtype t);
 
 /* Tuning knobs (no counterpart in the reference, whose choices are
- * compile-time constants). Every knob takes 0, 1 or 2. Known names:
+ * compile-time constants). The knobs take 0, 1 or 2 unless said otherwise.
+ * Known names:
  *   "trsv_wide"   1 (default) = systems with n >= 6144, 2- or 4-byte storage
  *                 and a 16-byte aligned matrix base and row stride use
  *                 128-row blocks
@@ -91,6 +92,12 @@ size_t accblas_dtype_size(accblas_dtype t);
  *                 a group walk the columns one chunk apart, against channel
  *                 aliasing of power-of-two pitches); 0 = never; 2 = whenever
  *                 the shape allows it.
+ *   "trsv_wide_split_from"  (any count >= 0) the 128-row kernel gives the row
+ *                 blocks that cannot be resident from the start - those beyond
+ *                 the number of CUs - four workgroups each (helpers sum
+ *                 shares of the far columns, the owner adds their sums in a
+ *                 fixed order); 0 (default) = the device's CU count, k > 0 =
+ *                 as if the device had k CUs.
  * Unknown names and other values return ACCBLAS_ERR_INVALID_ARGUMENT. */
 int accblas_set_option(const char *name, int value);
 

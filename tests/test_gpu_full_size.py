@@ -186,6 +186,43 @@ def test_trsv_24000_matches_reference_shape_both_paths(gpu):
     assert rel_l1(torch, x_vec, x_scalar) <= 1e-6
 
 
+@pytest.mark.parametrize("ar,st", [(F64, F32), (F32, F16), (F64, F64)])
+@pytest.mark.parametrize("upper", [False, True])
+def test_trsv_split_row_blocks_match_oracle_and_unsplit_bits(gpu, ar, st, upper):
+    """The 128-row kernel with split row blocks (helpers sum shares of the far
+    columns of the blocks beyond the CU count; here forced from block 100 on, so
+    that n = 16200 exercises it): against the semantic oracle, bit-for-bit
+    repeatable, and with the SAME summation structure whatever the helpers'
+    timing (a second solve gives the same bits)."""
+    torch, accblas = gpu
+    n, lda = 16200, 16208
+    rng = np.random.default_rng(78)
+    full = rng.uniform(-1.0, 1.0, (n, lda)) / np.sqrt(n)
+    A = oracle.convert(full.reshape(-1), st)
+    b = oracle.convert(rng.uniform(-1.0, 1.0, n), st)
+    want = oracle.exact_trsv(ar, upper, True, n, A, lda, b, 1)
+    dA = torch.from_numpy(A).cuda()
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    uplo = accblas.UPPER if upper else accblas.LOWER
+    accblas.set_option("trsv_wide", 2)
+    accblas.set_option("trsv_wide_split_from", 100)
+    try:
+        runs = []
+        for _ in range(3):
+            dx = torch.from_numpy(b).cuda()
+            accblas.acc_trsv(ar, st, uplo, accblas.UNIT, n, dA, lda, dx, 1, helper)
+            torch.cuda.synchronize()
+            assert int(helper[0].item()) & 0xffffffff == 0xffffffff
+            runs.append(dx)
+    finally:
+        accblas.set_option("trsv_wide", 1)
+        accblas.set_option("trsv_wide_split_from", 0)
+    err = oracle.rel_error(want.astype(np.float64), runs[0].cpu().numpy().astype(np.float64))
+    tol = {F16: 1e-1, F32: 1e-5, F64: 1e-11}[st]
+    assert err <= tol, err
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+
+
 @pytest.mark.parametrize("wide", [0, 2])
 @pytest.mark.parametrize("upper", [False, True])
 @pytest.mark.parametrize("unit", [True, False])

@@ -525,8 +525,10 @@ def test_caller_owned_workspace(gpu, trsv_kernel):
     torch, accblas = gpu
     n, small = 3000, 700
     size = accblas.trsv_workspace_bytes(F32, n)
-    assert size == 4096 + 8 * n
-    assert accblas.trsv_workspace_bytes(F64, n) == 4096 + 16 * n
+    def expected(words):  # header + x granules (64-word aligned) + partial-sum area
+        return 4096 + 8 * (-(-n * words // 64) * 64 + -(-n // 128) * 7 * 128 * 2)
+    assert size == expected(1)
+    assert accblas.trsv_workspace_bytes(F64, n) == expected(2)
     workspace = torch.empty(size, dtype=torch.uint8, device="cuda")
     workspace.fill_(0xAB)  # garbage: init must arm it
     accblas.trsv_workspace_init(workspace)
