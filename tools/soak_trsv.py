@@ -17,7 +17,7 @@ F16, F32, F64 = accblas.F16, accblas.F32, accblas.F64
 
 def main(iterations=4000, seed=7):
     rng = np.random.default_rng(seed)
-    max_n = 6000
+    max_n = 14000  # 110 row blocks of 128: the split blocks can be exercised
     scale = 1.0 / np.sqrt(max_n)
     base = (torch.rand(max_n * max_n, dtype=torch.float64, device="cuda") * 2 - 1) * scale
     mats = {F64: base, F32: base.float(), F16: base.half()}
@@ -30,6 +30,11 @@ def main(iterations=4000, seed=7):
         ar = F64 if st == F64 or rng.integers(0, 2) else F32
         upper = bool(rng.integers(0, 2))
         which = it % 2
+        # kernel family: automatic / 64-row only / 128-row wherever possible,
+        # the latter now and then with split row blocks (helpers from block 98)
+        family = int(rng.integers(0, 4))
+        accblas.set_option("trsv_wide", (1, 0, 2, 2)[family])
+        accblas.set_option("trsv_wide_split_from", 98 if family == 3 else 0)
         A = mats[st]
         dtype = accblas.torch_dtype(st)
         with torch.cuda.stream(streams[which]):
@@ -53,6 +58,8 @@ def main(iterations=4000, seed=7):
             print(f"iteration {it + 1}: ok (n={n}, st={accblas.DTYPE_NAMES[st]}, "
                   f"residual {float(res):.2e})", flush=True)
     torch.cuda.synchronize()
+    accblas.set_option("trsv_wide", 1)
+    accblas.set_option("trsv_wide_split_from", 0)
     print(f"soak passed: {iterations} solves, worst checked residual {worst:.2e}")
 
 
