@@ -67,13 +67,13 @@ int trsv_split_from_option_value();
 int trsv_relay_option_value();
 
 /** From this size on the 128-row kernel is the faster one for 2- and 4-byte
- *  storage (profiles/r02_trsv_rows64_vs_rows128.txt: equal at n = 4096, 12-20 %
- *  faster at 8192, 20-50 % at 24000-65536). With 8-byte storage the two are
+ *  storage (profiles/r02_trsv_ab_final.txt: 4-7 % faster at n = 4096, 17-20 %
+ *  at 8192, 27-50 % at 24000-65536). With 8-byte storage the two are
  *  within 2 % of each other at every size (the 128-row kernel then has
  *  registers for two half-width steps in flight only), so the automatic rule
  *  keeps the 64-row kernel there. */
 #ifndef ACCBLAS_TRSV_WIDE_MIN_N
-#define ACCBLAS_TRSV_WIDE_MIN_N 6144
+#define ACCBLAS_TRSV_WIDE_MIN_N 4096
 #endif
 
 

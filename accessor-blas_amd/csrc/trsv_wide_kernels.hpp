@@ -17,7 +17,7 @@
 //     X10 = -X11 (D10 X00) as two 64 x 64 x 64 products on the matrix cores;
 //   * the 128 x 128 panel next to the diagonal is folded with the inverse,
 //     W = inv(T) A_{b,b-1} (a 128^3 product on the matrix cores, the panel
-//     passing through LDS in four chunks of 32 rows), so
+//     operand read straight from global memory one pass ahead), so
 //     x_b = inv(T) rhs_far - W x_{b-1}: BOTH 64-row halves of x_b follow from
 //     x_{b-1} in one step, there is no hop between them;
 //   * W is computed TRANSPOSED (W^T = A^T inv(T)^T), which leaves it in the
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
 
     // tiles[0] = D00 -> X00, tiles[1] = D11 -> X11 (inverses column-major,
     // tile[c * ld + r]), tiles[2] = D10 (row-major) -> X10 (column-major),
-    // tiles[3] = scratch: inversion, Y = D10 X00, panel chunks
+    // tiles[3] = scratch: inversion, Y = D10 X00; later the x chunks
     __shared__ __attribute__((aligned(16))) ar_type tiles[4][H * ld];
     __shared__ ar_type own_lds[R];
     __shared__ ar_type rhs_lds[R];   // own - far correction
@@ -490,9 +490,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             }
         }
     }
+    __syncthreads();  // X10 complete: the inverse may be read from here on
     ACCBLAS_TRSV_WIDE_STAMP(15);  // X10 written
-    // readers of X10 and the next writers of tiles[3] wait at the barriers of
-    // the chunk loop below
 
     // inv(T)[row][k] for k <= row < 128 (k > row: zero, stored for k in the
     // row's own 64-column tile only)
@@ -513,7 +512,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     // ---- W = inv(T) A_{b,b-1}, transposed product, wave w = rows 16w.. -----
     // D[i][j] = sum_k P[k][16 tj + i] inv(T)[16 w + j][k] = W[16w + j][16tj + i]:
     // lane l ends with W[16w + (l & 15)][16 tj + mma::row(l, reg)] in
-    // w_acc[tj][reg]. The panel P passes through tiles[3] in chunks of 32 rows.
+    // w_acc[tj][reg].
     typename mma::acc_type w_acc[R / 16];
     // Workgroups with a long far sweep ahead of them compute W late (see
     // `deferred_columns`): during the bulk of the sweep its 64 registers hold
@@ -523,41 +522,53 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         for (int tj = 0; tj < R / 16; ++tj) {
             w_acc[tj] = typename mma::acc_type{};
         }
-        constexpr int KC = 32;             // panel rows per chunk
-        constexpr int per_thread = KC * R / (Waves * wave_size);  // 8
-        ar_type *chunk = tiles[3];         // chunk[kl * R + c]
+        // The panel operand comes straight from global memory (the eight
+        // waves read the same 64 KB: L1 / L2 hits), one pass of 16 panel rows
+        // ahead of the matrix core: no LDS staging, no barriers, every wave
+        // runs its own (tile + 1) passes back to back. (Through LDS in four
+        // 32-row chunks the fold took 15-23 us for 7.7 us of MFMA time.)
         const index_type prev = base - R;
-        for (int k0 = 0; k0 < R; k0 += KC) {
-            ar_type staged[per_thread];
+        using operand = std::remove_cv_t<st_type>;
+        const auto fetch = [&](int kp, operand (&a)[R / 16][4]) {
 #pragma unroll
-            for (int j = 0; j < per_thread; ++j) {
-                const int e = j * Waves * wave_size + threadIdx.x;
-                staged[j] = entry(base + k0 + e / R, prev + e % R);
-            }
-            __syncthreads();  // previous chunk (or Y / X10 writes) done
-#pragma unroll
-            for (int j = 0; j < per_thread; ++j) {
-                const int e = j * Waves * wave_size + threadIdx.x;
-                chunk[e] = staged[j];
-            }
-            __syncthreads();
-            for (int kp = k0; kp < k0 + KC && kp < k_end; kp += 16) {
-                ar_type b[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    b[q] = inv_entry(own_tile_row, kp + q * 4 + fk);
-                }
+            for (int q = 0; q < 4; ++q) {
+                const index_type gr = base + kp + q * 4 + fk;
+                const index_type row = phys(gr < n ? gr : n - 1);
 #pragma unroll
                 for (int tj = 0; tj < R / 16; ++tj) {
-                    ar_type a[4];
+                    // rows that do not exist are masked below
+                    a[tj][q] = a_data[row * lda + phys(prev + 16 * tj + fi)];
+                }
+            }
+        };
+        operand a_now[R / 16][4];
+        operand a_next[R / 16][4];
+        fetch(0, a_now);
+        for (int kp = 0; kp < k_end; kp += 16) {
+            if (kp + 16 < k_end) {
+                fetch(kp + 16, a_next);
+            }
+            ar_type b[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        a[q] = chunk[(kp - k0 + q * 4 + fk) * R + 16 * tj + fi];
-                    }
+            for (int q = 0; q < 4; ++q) {
+                b[q] = inv_entry(own_tile_row, kp + q * 4 + fk);
+                if (base + kp + q * 4 + fk >= n) {
+                    b[q] = ar_type{};  // panel row beyond the matrix
+                }
+            }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        w_acc[tj] = mma::step(a[q], b[q], w_acc[tj]);
-                    }
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int tj = 0; tj < R / 16; ++tj) {
+                    w_acc[tj] = mma::step(static_cast<ar_type>(a_now[tj][q]),
+                                          b[q], w_acc[tj]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int tj = 0; tj < R / 16; ++tj) {
+                    a_now[tj][q] = a_next[tj][q];
                 }
             }
         }
@@ -872,7 +883,6 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             sweep(std::integral_constant<int, DeepDepth>{}, swept, bulk_end);
             swept = bulk_end;
         }
-        lds_barrier();  // x_chunk shares tiles[3] with the panel chunks
         fold_panel();
         if (parts_here > 1 && threadIdx.x < R) {
             // the helpers' partial sums, added in part order: they are

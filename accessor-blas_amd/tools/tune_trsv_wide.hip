@@ -114,7 +114,7 @@ int main(int argc, char **argv)
     auto us = [&](unsigned b, int w, int slot) {
         return (double)(long long)(s[(size_t(b) * 8 + w) * 20 + slot] - t0) * 0.01;
     };
-    for (unsigned b : {0u, 1u, 2u, 100u}) {
+    for (unsigned b : {0u, 1u, 8u, 50u, 100u}) {
         if (b >= blocks) continue;
         std::printf("prologue %3u (w0 / w1 / w7): start %.2f | ticket %.2f %.2f %.2f | staged %.2f %.2f %.2f | "
                     "inverted %.2f %.2f %.2f | X10 %.2f %.2f %.2f | W or sweep start %.2f %.2f %.2f\n",
