@@ -386,7 +386,8 @@ def test_plain_trsv_equals_accessor_bitwise(gpu, trsv_kernel, vt, upper):
     assert torch.equal(x1, x2)
 
 
-def test_trsv_manufactured_solution_strided(gpu):
+@pytest.mark.parametrize("trsv_kernel", ["rows64", "rows128"], indirect=True)
+def test_trsv_manufactured_solution_strided(gpu, trsv_kernel):
     """b = T x_true formed in high precision; the solve returns x_true
     (SURVEY.md §8c C-4), with incx != 1."""
     torch, accblas = gpu
@@ -578,7 +579,8 @@ def test_caller_owned_workspace(gpu, trsv_kernel):
     assert torch.equal(got, want)
 
 
-def test_trsv_concurrent_streams_and_host_threads(gpu):
+@pytest.mark.parametrize("trsv_kernel", ["rows64", "rows128"], indirect=True)
+def test_trsv_concurrent_streams_and_host_threads(gpu, trsv_kernel):
     """Solves on different streams use different workspaces and may overlap on
     the device; two host threads may drive them at the same time."""
     import threading
