@@ -66,14 +66,16 @@ int trsv_split_from_option_value();
 /** Option "trsv_relay": 0 never, 1 by the measured rule (default), 2 always. */
 int trsv_relay_option_value();
 
-/** From this size on the 128-row kernel is the faster one for 2- and 4-byte
- *  storage (profiles/r02_trsv_ab_final.txt: 4-7 % faster at n = 4096, 17-20 %
- *  at 8192, 27-50 % at 24000-65536). With 8-byte storage the two are
- *  within 2 % of each other at every size (the 128-row kernel then has
- *  registers for two half-width steps in flight only), so the automatic rule
- *  keeps the 64-row kernel there. */
+/** From these sizes on the 128-row kernel is the faster one
+ *  (profiles/r02_trsv_ab_final.txt): 2- and 4-byte storage 4-7 % faster at
+ *  n = 4096, 17-20 % at 8192, 27-50 % at 24000-65536; 8-byte storage (two
+ *  half-width steps in flight are all the registers allow) 3-4 % at 16384,
+ *  24000 and 65536, equal at 32768 (profiles/r02_trsv_f64_storage_ab.txt). */
 #ifndef ACCBLAS_TRSV_WIDE_MIN_N
 #define ACCBLAS_TRSV_WIDE_MIN_N 4096
+#endif
+#ifndef ACCBLAS_TRSV_WIDE_MIN_N_8BYTE
+#define ACCBLAS_TRSV_WIDE_MIN_N_8BYTE 16384
 #endif
 
 
@@ -113,8 +115,9 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
     const int wide = trsv_wide_option_value();
     const bool use_wide =
         wide != 0 && dev::trsv_wide_applicable(upper, mtx) &&
-        (wide == 2 ||
-         (sizeof(st_type) < 8 && n >= ACCBLAS_TRSV_WIDE_MIN_N));
+        (wide == 2 || n >= (sizeof(st_type) < 8
+                                ? ACCBLAS_TRSV_WIDE_MIN_N
+                                : ACCBLAS_TRSV_WIDE_MIN_N_8BYTE));
     if (use_wide) {
         return check_hip(
             dev::launch_trsv_wide<ar_type>(upper, unit_diag, mtx, x, helper,

@@ -76,9 +76,9 @@ size_t accblas_dtype_size(accblas_dtype t);
 /* Tuning knobs (no counterpart in the reference, whose choices are
  * compile-time constants). The knobs take 0, 1 or 2 unless said otherwise.
  * Known names:
- *   "trsv_wide"   1 (default) = systems with n >= 4096, 2- or 4-byte storage
- *                 and a 16-byte aligned matrix base and row stride use
- *                 128-row blocks
+ *   "trsv_wide"   1 (default) = systems with n >= 4096 (8-byte storage:
+ *                 n >= 16384) and a 16-byte aligned matrix base and row
+ *                 stride use 128-row blocks
  *                 (`kernel::trsv_wide`: half as many dependent hops through
  *                 memory, the folded panel held in registers), everything
  *                 else 64-row blocks (`kernel::trsv`); 0 = 64-row blocks only;
