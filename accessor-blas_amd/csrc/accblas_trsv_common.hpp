@@ -60,8 +60,8 @@ int trsv_num_cus();
 /** Option "trsv_wide": 0 = 64-row kernel only, 1 = 128-row kernel by the
  *  measured rule (default), 2 = 128-row kernel whenever the operands allow. */
 int trsv_wide_option_value();
-/** Option "trsv_wide_split_from": 0 = split the row blocks beyond the CU count
- *  (default), k > 0 = as if the device had k CUs (tests, experiments). */
+/** Option "trsv_wide_split_from": 0 = the first split row block by the rule
+ *  (`trsv_wide_split_for`, default), k > 0 = block k (tests, experiments). */
 int trsv_split_from_option_value();
 /** Option "trsv_relay": 0 never, 1 by the measured rule (default), 2 always. */
 int trsv_relay_option_value();
@@ -122,9 +122,8 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
         return check_hip(
             dev::launch_trsv_wide<ar_type>(upper, unit_diag, mtx, x, helper,
                                            session, as_stream(stream),
-                                           trsv_split_from_option_value() > 0
-                                               ? trsv_split_from_option_value()
-                                               : trsv_num_cus()),
+                                           trsv_num_cus(),
+                                           trsv_split_from_option_value()),
             "trsv (128-row) launch");
     }
     return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x, helper,

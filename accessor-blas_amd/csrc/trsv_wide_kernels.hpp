@@ -71,6 +71,7 @@ struct trsv_wide_split {
     int parts;
     int tail_block;  // blocks from here on have `tail_parts` workgroups each
     int tail_parts;  // (smaller shares: the last tickets run almost alone)
+    int tail_deferred;  // block columns the owner of a tail block keeps
 };
 constexpr int trsv_wide_max_parts = 8;
 
@@ -98,6 +99,9 @@ constexpr index_type trsv_wide_partial_offset(index_type n, int words_per_elemen
 // is never built with it.
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
 __device__ unsigned long long *trsv_wide_diag_buffer;
+// one record per workgroup, (block * 8 + part) * 8 words: start, sweep start,
+// first time at the front, block column then, end, first column, end column
+__device__ unsigned long long *trsv_wide_diag_workgroups;
 #define ACCBLAS_TRSV_WIDE_STAMP(_slot) diag_stamp[_slot] = wall_clock64()
 #else
 #define ACCBLAS_TRSV_WIDE_STAMP(_slot) \
@@ -308,6 +312,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     __shared__ __attribute__((aligned(16))) ar_type tiles[4][H * ld];
     __shared__ ar_type own_lds[R];
     __shared__ ar_type rhs_lds[R];   // own - far correction
+    __shared__ ar_type join_lds[trsv_wide_max_parts - 1][R];  // helpers' sums
     __shared__ __attribute__((aligned(16))) st_type x_perm[R];    // x_{b-1} in the order the lanes read it
     __shared__ std::int32_t shared_block;
     __shared__ std::int32_t shared_part;  // part of the block, parts - 1 = owner
@@ -575,8 +580,13 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     };
     // block columns that are swept after W has been computed when W is
     // deferred (W takes ~10 us; the chain's front must still be far away)
-    constexpr index_type deferred_columns = trsv_wide_deferred_columns;
-    const bool defer_fold = block - 1 >= 2 * deferred_columns;
+    const bool defer_fold = block - 1 >= 2 * trsv_wide_deferred_columns;
+    // (the owners of the last blocks start when the front has already passed
+    // most of what they would keep, and sweep it with the shallow ring)
+    const index_type deferred_columns =
+        (split.parts > 1 && block >= split.tail_block)
+            ? index_type{split.tail_deferred}
+            : trsv_wide_deferred_columns;
     // The first few blocks are due before a fold (~14 us) could finish: they
     // treat x_{b-1} as one more far column (a reduction and the c mat-vec on
     // their hop, ~0.6 us more) and start the chain ~15 us earlier.
@@ -798,6 +808,12 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             }
             lds_barrier();
         } else {
+#ifdef ACCBLAS_TRSV_WIDE_DIAG
+            if (diag_stamp[16] == 0) {
+                diag_stamp[16] = wall_clock64();
+                diag_stamp[17] = static_cast<unsigned long long>(column);
+            }
+#endif
             at_front = true;  // from now on the columns come one at a time
         }
         chunk_first = column;
@@ -874,6 +890,50 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                            total, epoch);
         }
     } else {
+    // the helpers' partial sums, added in part order: they are subtracted from
+    // this row's right-hand side before the sums of this workgroup's own
+    // columns (a fixed order, whatever the timing)
+    const auto join_helpers = [&]() __attribute__((always_inline)) {
+        // thread t fetches parts t / 128 and t / 128 + 4 of row t % 128 (one
+        // round trip for all of them, two probes' worth of registers), a
+        // thread per row adds them up
+        if (parts_here > 1) {
+            constexpr int groups = Waves * wave_size / R;
+            static_assert(2 * groups >= trsv_wide_max_parts - 1, "two parts per thread");
+            const int row = threadIdx.x % R;
+            const int group = threadIdx.x / R;
+            const index_type slot0 =
+                (block * (trsv_wide_max_parts - 1)) * R + row;
+            granule_word raw[2][io_ar::words];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = group + j * groups;
+                if (p < parts_here - 1) {
+                    io_ar::load(partials, slot0 + p * R, raw[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = group + j * groups;
+                if (p < parts_here - 1) {
+                    while (!io_ar::ready(raw[j], epoch) &&
+                           !detail::spin_expired(spins, helper)) {
+                        __builtin_amdgcn_s_sleep(4);
+                        io_ar::load(partials, slot0 + p * R, raw[j]);
+                    }
+                    join_lds[p][row] = io_ar::decode(raw[j]);
+                }
+            }
+            lds_barrier();
+            if (threadIdx.x < R) {
+                ar_type helped{};
+                for (int p = 0; p < parts_here - 1; ++p) {
+                    helped += join_lds[p][threadIdx.x];
+                }
+                own_lds[threadIdx.x] -= helped;
+            }
+        }
+    };
     if (defer_fold) {
         // the bulk of a long sweep, W not yet computed: a deeper ring. The
         // per-CU streaming rate of the workgroups that start late bounds a
@@ -884,33 +944,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             swept = bulk_end;
         }
         fold_panel();
-        if (parts_here > 1 && threadIdx.x < R) {
-            // the helpers' partial sums, added in part order: they are
-            // subtracted from this row's right-hand side before the sums of
-            // this workgroup's own share (a fixed order, whatever the timing)
-            const index_type slot0 =
-                (block * (trsv_wide_max_parts - 1)) * R + threadIdx.x;
-            granule_word raw[trsv_wide_max_parts - 1][io_ar::words];
-#pragma unroll
-            for (int p = 0; p < trsv_wide_max_parts - 1; ++p) {
-                if (p < parts_here - 1) {
-                    io_ar::load(partials, slot0 + p * R, raw[p]);
-                }
-            }
-            ar_type helped{};
-#pragma unroll
-            for (int p = 0; p < trsv_wide_max_parts - 1; ++p) {
-                if (p < parts_here - 1) {
-                    while (!io_ar::ready(raw[p], epoch) &&
-                           !detail::spin_expired(spins, helper)) {
-                        __builtin_amdgcn_s_sleep(4);
-                        io_ar::load(partials, slot0 + p * R, raw[p]);
-                    }
-                    helped += io_ar::decode(raw[p]);
-                }
-            }
-            own_lds[threadIdx.x] -= helped;
-        }
+        join_helpers();
         lds_barrier();
         at_front = false;  // the front moved on meanwhile: catch up in bulk
         chunk_end_step = swept;
@@ -1010,11 +1044,23 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     ACCBLAS_TRSV_WIDE_STAMP(9);  // published
     }  // owner
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
-    if (lane == 0 && trsv_wide_diag_buffer != nullptr) {
+    if (lane == 0 && trsv_wide_diag_buffer != nullptr && !helper_part) {
         for (int i = 0; i < 20; ++i) {
             trsv_wide_diag_buffer[(block * Waves + wave_u) * 20 + i] =
                 diag_stamp[i];
         }
+    }
+    if (threadIdx.x == 0 && trsv_wide_diag_workgroups != nullptr) {
+        unsigned long long *record =
+            trsv_wide_diag_workgroups + (block * 8 + part) * 8;
+        record[0] = diag_stamp[0];
+        record[1] = helper_part ? diag_stamp[12] : diag_stamp[1];
+        record[2] = diag_stamp[16];
+        record[3] = diag_stamp[17];
+        record[4] = wall_clock64();
+        record[5] = static_cast<unsigned long long>(first_column);
+        record[6] = static_cast<unsigned long long>(far_columns);
+        record[7] = 1;
     }
 #endif
 
@@ -1099,33 +1145,56 @@ bool trsv_wide_applicable(bool upper, const MtxView &mtx)
 #define ACCBLAS_TRSV_WIDE_TAIL_PARTS 8
 #endif
 #ifndef ACCBLAS_TRSV_WIDE_TAIL_BLOCKS
-#define ACCBLAS_TRSV_WIDE_TAIL_BLOCKS 64
+#define ACCBLAS_TRSV_WIDE_TAIL_BLOCKS 32
+#endif
+#ifndef ACCBLAS_TRSV_WIDE_TAIL_DEFERRED
+#define ACCBLAS_TRSV_WIDE_TAIL_DEFERRED 16
+#endif
+#ifndef ACCBLAS_TRSV_WIDE_WHOLE_BLOCKS
+#define ACCBLAS_TRSV_WIDE_WHOLE_BLOCKS 64
 #endif
 
 /** How a solve of n unknowns is split on a device with `num_cus` CUs: row
  *  blocks that cannot be resident from the start (more blocks than CUs) get
  *  ACCBLAS_TRSV_WIDE_PARTS workgroups each (4 helpers + the owner), the last
- *  ACCBLAS_TRSV_WIDE_TAIL_BLOCKS of them ACCBLAS_TRSV_WIDE_TAIL_PARTS: the
+ *  ACCBLAS_TRSV_WIDE_TAIL_BLOCKS of them ACCBLAS_TRSV_WIDE_TAIL_PARTS, their
+ *  owners keeping ACCBLAS_TRSV_WIDE_TAIL_DEFERRED block columns only: the
  *  workgroups with the last tickets run almost alone, so their shares decide
  *  how long the solve's tail is. Measured (profiles/r02_trsv_split_ab.txt,
  *  us, unsplit -> 5 parts -> 5 parts + 8 for the last 64 blocks):
  *  n = 40000: 845-863 -> 747-785 -> 748-778; n = 65536: 1554 -> 1563-1608 ->
- *  1496-1500. */
-inline trsv_wide_split trsv_wide_split_for(index_type n, int num_cus)
+ *  1496-1500; the other tail shapes tried since are within 2 % of each other
+ *  (profiles/r02_trsv_split_first.txt). */
+inline trsv_wide_split trsv_wide_split_for(index_type n, int num_cus,
+                                           int split_from = 0)
 {
     const int blocks = static_cast<int>(ceildiv(n, index_type{trsv_wide_rows}));
     // a split block must defer its fold (2 x deferred + 1 far columns at least)
     constexpr int min_first = 2 * static_cast<int>(trsv_wide_deferred_columns) + 2;
-    const int first = num_cus > min_first ? num_cus : min_first;
+    // The first blocks beyond the CU count stay whole: the owner of a split
+    // block starts when the front is still far away (a CU frees up per hop AND
+    // per finished helper) and then holds its CU idle, a whole block that
+    // starts early sweeps its own columns meanwhile. Up to 64 of them, half of
+    // what there is (profiles/r02_trsv_split_first.txt: first split block
+    // 256 -> 320 at n = 49152 / 57344 / 65536: 965 -> 922, 1190 -> 1128,
+    // 1447 -> 1414 us; n = 40000, 313 blocks: 288 as good as 256, none worse)
+    int whole = blocks > num_cus ? (blocks - num_cus) / 2 : 0;
+    whole = whole < ACCBLAS_TRSV_WIDE_WHOLE_BLOCKS ? whole
+                                                   : ACCBLAS_TRSV_WIDE_WHOLE_BLOCKS;
+    // (`split_from` > 0: the caller's choice of the first split block)
+    const int wanted = split_from > 0 ? split_from : num_cus + whole;
+    const int first = wanted > min_first ? wanted : min_first;
     if (ACCBLAS_TRSV_WIDE_PARTS > 1 && blocks > first) {
         const int tail_blocks = ACCBLAS_TRSV_WIDE_TAIL_BLOCKS < blocks - first
                                     ? ACCBLAS_TRSV_WIDE_TAIL_BLOCKS
                                     : blocks - first;
         return trsv_wide_split{first, ACCBLAS_TRSV_WIDE_PARTS,
                                blocks - tail_blocks,
-                               ACCBLAS_TRSV_WIDE_TAIL_PARTS};
+                               ACCBLAS_TRSV_WIDE_TAIL_PARTS,
+                               ACCBLAS_TRSV_WIDE_TAIL_DEFERRED};
     }
-    return trsv_wide_split{blocks, 1, blocks, 1};
+    return trsv_wide_split{blocks, 1, blocks, 1,
+                           static_cast<int>(trsv_wide_deferred_columns)};
 }
 
 /** Workgroups a solve launches under `split`. */
@@ -1141,7 +1210,7 @@ template <typename ArType, typename MtxView, typename XView>
 hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
                             const XView &x, std::uint32_t *helper,
                             const trsv_session &session, hipStream_t stream,
-                            int num_cus)
+                            int num_cus, int split_from = 0)
 {
     using st_type =
         std::remove_cv_t<typename view_traits<XView>::storage_type>;
@@ -1167,7 +1236,7 @@ hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
     // (`defer_fold`, helpers of split blocks): as deep as the registers allow.
     constexpr int depth = sizeof(st_type) == 2 ? 3 : 2;
     constexpr int deep_depth = sizeof(st_type) == 2 ? 5 : 4;
-    const trsv_wide_split split = trsv_wide_split_for(n, num_cus);
+    const trsv_wide_split split = trsv_wide_split_for(n, num_cus, split_from);
     const dim3 grid(trsv_wide_grid(n, split));
     const dim3 block(trsv_wide_waves * wave_size);
     const unsigned pad = trsv_wide_single_block_pad<ArType>();

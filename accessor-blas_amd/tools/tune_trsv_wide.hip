@@ -105,6 +105,10 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&diag, size_t(blocks) * 8 * 20 * 8));
     CHECK(hipMemset(diag, 0, size_t(blocks) * 8 * 20 * 8));
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_wide_diag_buffer), &diag, sizeof(diag)));
+    unsigned long long *records;
+    CHECK(hipMalloc(&records, size_t(blocks) * 8 * 8 * 8));
+    CHECK(hipMemset(records, 0, size_t(blocks) * 8 * 8 * 8));
+    CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_wide_diag_workgroups), &records, sizeof(records)));
     CHECK(hipMemcpy(x, x0, n * sizeof(st_type), hipMemcpyDeviceToDevice));
     entries[1].run();
     CHECK(hipDeviceSynchronize());
@@ -134,6 +138,62 @@ int main(int argc, char **argv)
                     us(b, 0, 9), us(b, 7, 9),
                     b ? pub(b) - pub(b - 1) : 0.0, b ? us(b, 0, 6) - pub(b - 1) : 0.0,
                     b ? pub(b) - us(b, 0, 6) : 0.0, b > 1 ? std::max(us(b, 0, 5), us(b, 7, 5)) - pub(b - 2) : 0.0);
+    }
+    // where the bytes flow: every workgroup's columns, spread over the time it
+    // caught up in bulk and then placed at the moments the front handed them over
+    {
+        std::vector<unsigned long long> rec(size_t(blocks) * 64);
+        CHECK(hipMemcpy(rec.data(), records, rec.size() * 8, hipMemcpyDeviceToHost));
+        auto t_of = [&](unsigned long long v) { return (double)(long long)(v - t0) * 0.01; };
+        std::vector<double> pubt(blocks);
+        for (unsigned b = 0; b < blocks; ++b) pubt[b] = pub(b);
+        const double bucket = argc > 3 ? std::atof(argv[3]) : 50.0;
+        const double total = pubt[blocks - 1];
+        const int buckets = int(total / bucket) + 2;
+        std::vector<double> tiles(buckets, 0.0), resident(buckets, 0.0), following(buckets, 0.0);
+        auto add = [&](double t, double amount) {
+            int i = int(t / bucket);
+            i = std::min(std::max(i, 0), buckets - 1);
+            tiles[i] += amount;
+        };
+        auto add_span = [&](double a, double b, double amount, std::vector<double> &into, bool rate) {
+            if (b <= a) { b = a + 0.01; }
+            for (int i = std::max(0, int(a / bucket)); i < buckets && i * bucket < b; ++i) {
+                const double lo = std::max(a, i * bucket), hi = std::min(b, (i + 1) * bucket);
+                if (hi > lo) into[i] += rate ? amount * (hi - lo) / bucket : amount * (hi - lo) / (b - a);
+            }
+        };
+        for (unsigned b = 0; b < blocks; ++b) {
+            for (int p = 0; p < 8; ++p) {
+                const unsigned long long *r = &rec[(size_t(b) * 8 + p) * 8];
+                if (r[7] != 1) continue;
+                const double start = t_of(r[0]), sweep0 = t_of(r[1]), end = t_of(r[4]);
+                const long c0 = long(r[5]), c1 = long(r[6]);
+                add_span(start, end, 1.0, resident, true);
+                if (r[2] == 0) {
+                    add_span(sweep0, end, double(std::max(0L, c1 - c0)), tiles, false);
+                } else {
+                    const double tf = t_of(r[2]);
+                    const long cf = long(r[3]);
+                    add_span(sweep0, tf, double(std::max(0L, cf - c0)), tiles, false);
+                    for (long c = cf; c < c1; ++c) add(std::max(pubt[c], tf), 1.0);
+                    add_span(tf, end, 1.0, following, true);
+                }
+            }
+            add(pubt[b], b > 0 ? 1.5 : 0.5);  // folded panel + triangle
+        }
+        std::printf("bytes over time (%.0f us buckets): start us | TB/s | front (row blocks published) | "
+                    "workgroups resident | of them at the front\n", bucket);
+        double sum = 0;
+        for (int i = 0; i < buckets; ++i) {
+            unsigned front = 0;
+            while (front < blocks && pubt[front] <= (i + 1) * bucket) ++front;
+            sum += tiles[i];
+            std::printf("  %7.0f | %5.2f | %4u | %6.1f | %6.1f\n", i * bucket,
+                        tiles[i] * 128.0 * 128.0 * sizeof(st_type) / (bucket * 1e-6) / 1e12, front,
+                        resident[i], following[i]);
+        }
+        std::printf("  accounted: %.3f GB of %.3f GB\n", sum * 128.0 * 128.0 * sizeof(st_type) / 1e9, bytes / 1e9);
     }
     std::uint32_t h[2];
     CHECK(hipMemcpy(h, helper, 8, hipMemcpyDeviceToHost));

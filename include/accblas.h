@@ -94,10 +94,11 @@ size_t accblas_dtype_size(accblas_dtype t);
  *                 the shape allows it.
  *   "trsv_wide_split_from"  (any count >= 0) the 128-row kernel gives the row
  *                 blocks that cannot be resident from the start - those beyond
- *                 the number of CUs - four workgroups each (helpers sum
- *                 shares of the far columns, the owner adds their sums in a
- *                 fixed order); 0 (default) = the device's CU count, k > 0 =
- *                 as if the device had k CUs.
+ *                 the number of CUs, except the first (up to 64) of them -
+ *                 several workgroups each (helpers sum shares of the far
+ *                 columns, the owner adds their sums in a fixed order);
+ *                 0 (default) = that rule, k > 0 = from row block k on (at
+ *                 least 98).
  * Unknown names and other values return ACCBLAS_ERR_INVALID_ARGUMENT. */
 int accblas_set_option(const char *name, int value);
 
