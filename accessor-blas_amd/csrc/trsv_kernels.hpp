@@ -1066,16 +1066,21 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
 }  // namespace kernel
 
 
+/** Helpers a split row block of the 128-row kernel can have (one slot of 128
+ *  partial sums each in the workspace). */
+constexpr int trsv_partial_slots = 7;
+
 /** Bytes of hand-off workspace a solve of n unknowns needs behind the state
  *  header: one or two granule words per element of x, then (128-row kernel,
- *  split row blocks) the partial-sum area: 7 x 128 two-word slots per 128-row
- *  block, 64-word aligned. */
+ *  split row blocks) the partial-sum area: `trsv_partial_slots` x 128
+ *  two-word slots per 128-row block, 64-word aligned. */
 template <typename St>
 constexpr std::size_t trsv_workspace_bytes(index_type n)
 {
     const index_type x_words =
         ceildiv(n * trsv_granule_words<St>(), index_type{64}) * 64;
-    const index_type partial_words = ceildiv(n, index_type{128}) * 7 * 128 * 2;
+    const index_type partial_words =
+        ceildiv(n, index_type{128}) * trsv_partial_slots * 128 * 2;
     return static_cast<std::size_t>(x_words + partial_words) *
            sizeof(granule_word);
 }

@@ -73,7 +73,7 @@ struct trsv_wide_split {
     int tail_parts;  // (smaller shares: the last tickets run almost alone)
     int tail_deferred;  // block columns the owner of a tail block keeps
 };
-constexpr int trsv_wide_max_parts = 8;
+constexpr int trsv_wide_max_parts = trsv_partial_slots + 1;
 
 /** Granule words of the partial-sum area that follows the x granules in the
  *  workspace: (parts - 1) x 128 partial sums per row block, one or two words
@@ -99,7 +99,7 @@ constexpr index_type trsv_wide_partial_offset(index_type n, int words_per_elemen
 // is never built with it.
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
 __device__ unsigned long long *trsv_wide_diag_buffer;
-// one record per workgroup, (block * 8 + part) * 8 words: start, sweep start,
+// one record per workgroup, (block * 16 + part) * 8 words: start, sweep start,
 // first time at the front, block column then, end, first column, end column
 __device__ unsigned long long *trsv_wide_diag_workgroups;
 #define ACCBLAS_TRSV_WIDE_STAMP(_slot) diag_stamp[_slot] = wall_clock64()
@@ -894,26 +894,27 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     // this row's right-hand side before the sums of this workgroup's own
     // columns (a fixed order, whatever the timing)
     const auto join_helpers = [&]() __attribute__((always_inline)) {
-        // thread t fetches parts t / 128 and t / 128 + 4 of row t % 128 (one
-        // round trip for all of them, two probes' worth of registers), a
+        // thread t fetches parts t / 128, t / 128 + 4, ... of row t % 128 (one
+        // round trip for all of them, a few probes' worth of registers), a
         // thread per row adds them up
         if (parts_here > 1) {
             constexpr int groups = Waves * wave_size / R;
-            static_assert(2 * groups >= trsv_wide_max_parts - 1, "two parts per thread");
+            constexpr int per_thread =
+                (trsv_wide_max_parts - 1 + groups - 1) / groups;
             const int row = threadIdx.x % R;
             const int group = threadIdx.x / R;
             const index_type slot0 =
                 (block * (trsv_wide_max_parts - 1)) * R + row;
-            granule_word raw[2][io_ar::words];
+            granule_word raw[per_thread][io_ar::words];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < per_thread; ++j) {
                 const int p = group + j * groups;
                 if (p < parts_here - 1) {
                     io_ar::load(partials, slot0 + p * R, raw[j]);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < per_thread; ++j) {
                 const int p = group + j * groups;
                 if (p < parts_here - 1) {
                     while (!io_ar::ready(raw[j], epoch) &&
@@ -1052,7 +1053,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     }
     if (threadIdx.x == 0 && trsv_wide_diag_workgroups != nullptr) {
         unsigned long long *record =
-            trsv_wide_diag_workgroups + (block * 8 + part) * 8;
+            trsv_wide_diag_workgroups + (block * 16 + part) * 8;
         record[0] = diag_stamp[0];
         record[1] = helper_part ? diag_stamp[12] : diag_stamp[1];
         record[2] = diag_stamp[16];
@@ -1206,11 +1207,15 @@ inline unsigned trsv_wide_grid(index_type n, const trsv_wide_split &split)
         (blocks - split.tail_block) * split.tail_parts);
 }
 
+/** The 128-row kernel under an explicit `split` (tools; the library goes
+ *  through `launch_trsv_wide`). */
 template <typename ArType, typename MtxView, typename XView>
-hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
-                            const XView &x, std::uint32_t *helper,
-                            const trsv_session &session, hipStream_t stream,
-                            int num_cus, int split_from = 0)
+hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
+                                  const MtxView &mtx, const XView &x,
+                                  std::uint32_t *helper,
+                                  const trsv_session &session,
+                                  hipStream_t stream,
+                                  const trsv_wide_split &split)
 {
     using st_type =
         std::remove_cv_t<typename view_traits<XView>::storage_type>;
@@ -1224,6 +1229,10 @@ hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
     if (n <= 0) {
         return hipSuccess;
     }
+    if (split.parts > trsv_wide_max_parts ||
+        split.tail_parts > trsv_wide_max_parts) {
+        return hipErrorInvalidValue;
+    }
     constexpr int vec16 = 16 / sizeof(st_type);
     // a sweep step of 8-byte storage covers 64 columns: 16 load instructions
     // per lane and step would not leave registers for two steps in flight
@@ -1236,7 +1245,6 @@ hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
     // (`defer_fold`, helpers of split blocks): as deep as the registers allow.
     constexpr int depth = sizeof(st_type) == 2 ? 3 : 2;
     constexpr int deep_depth = sizeof(st_type) == 2 ? 5 : 4;
-    const trsv_wide_split split = trsv_wide_split_for(n, num_cus, split_from);
     const dim3 grid(trsv_wide_grid(n, split));
     const dim3 block(trsv_wide_waves * wave_size);
     const unsigned pad = trsv_wide_single_block_pad<ArType>();
@@ -1259,6 +1267,17 @@ hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
     }
 #undef ACCBLAS_TRSV_WIDE_LAUNCH
     return hipGetLastError();
+}
+
+template <typename ArType, typename MtxView, typename XView>
+hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
+                            const XView &x, std::uint32_t *helper,
+                            const trsv_session &session, hipStream_t stream,
+                            int num_cus, int split_from = 0)
+{
+    return launch_trsv_wide_split<ArType>(
+        upper, unit_diag, mtx, x, helper, session, stream,
+        trsv_wide_split_for(mtx.length(0), num_cus, split_from));
 }
 
 

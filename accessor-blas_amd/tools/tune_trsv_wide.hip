@@ -106,8 +106,8 @@ int main(int argc, char **argv)
     CHECK(hipMemset(diag, 0, size_t(blocks) * 8 * 20 * 8));
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_wide_diag_buffer), &diag, sizeof(diag)));
     unsigned long long *records;
-    CHECK(hipMalloc(&records, size_t(blocks) * 8 * 8 * 8));
-    CHECK(hipMemset(records, 0, size_t(blocks) * 8 * 8 * 8));
+    CHECK(hipMalloc(&records, size_t(blocks) * 16 * 8 * 8));
+    CHECK(hipMemset(records, 0, size_t(blocks) * 16 * 8 * 8));
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_wide_diag_workgroups), &records, sizeof(records)));
     CHECK(hipMemcpy(x, x0, n * sizeof(st_type), hipMemcpyDeviceToDevice));
     entries[1].run();
@@ -142,7 +142,7 @@ int main(int argc, char **argv)
     // where the bytes flow: every workgroup's columns, spread over the time it
     // caught up in bulk and then placed at the moments the front handed them over
     {
-        std::vector<unsigned long long> rec(size_t(blocks) * 64);
+        std::vector<unsigned long long> rec(size_t(blocks) * 128);
         CHECK(hipMemcpy(rec.data(), records, rec.size() * 8, hipMemcpyDeviceToHost));
         auto t_of = [&](unsigned long long v) { return (double)(long long)(v - t0) * 0.01; };
         std::vector<double> pubt(blocks);
@@ -164,8 +164,8 @@ int main(int argc, char **argv)
             }
         };
         for (unsigned b = 0; b < blocks; ++b) {
-            for (int p = 0; p < 8; ++p) {
-                const unsigned long long *r = &rec[(size_t(b) * 8 + p) * 8];
+            for (int p = 0; p < 16; ++p) {
+                const unsigned long long *r = &rec[(size_t(b) * 16 + p) * 8];
                 if (r[7] != 1) continue;
                 const double start = t_of(r[0]), sweep0 = t_of(r[1]), end = t_of(r[4]);
                 const long c0 = long(r[5]), c1 = long(r[6]);
@@ -194,6 +194,12 @@ int main(int argc, char **argv)
                         resident[i], following[i]);
         }
         std::printf("  accounted: %.3f GB of %.3f GB\n", sum * 128.0 * 128.0 * sizeof(st_type) / 1e9, bytes / 1e9);
+    }
+    // the last hops one by one: owner start, ready for the front (c), hop
+    std::printf("last row blocks: block | owner start | c ready | x_{b-1} seen - published | hop\n");
+    for (unsigned b = blocks > 96 ? blocks - 96 : 1; b < blocks; ++b) {
+        std::printf("  %4u | %8.2f | %8.2f | %6.2f | %6.2f\n", b, us(b, 0, 0),
+                    std::max(us(b, 0, 5), us(b, 7, 5)), us(b, 0, 6) - pub(b - 1), pub(b) - pub(b - 1));
     }
     std::uint32_t h[2];
     CHECK(hipMemcpy(h, helper, 8, hipMemcpyDeviceToHost));
