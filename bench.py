@@ -255,8 +255,10 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank):
             xs.copy_(b)
             accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, L, n, xs, 1, helper,
                              stream)
-        t_solve = event_time_us(accblas, torch, solve, stream, reps=3)
-        t_copy = event_time_us(accblas, torch, lambda: xs.copy_(b), stream, reps=3)
+        # (the reference's protocol: warm-up, then the minimum of 10 runs,
+        # cuda/utils.cuh:236-262)
+        t_solve = event_time_us(accblas, torch, solve, stream, reps=10)
+        t_copy = event_time_us(accblas, torch, lambda: xs.copy_(b), stream, reps=10)
         solve()
         torch.cuda.synchronize()
         # residual of 256 sampled rows in fp64: (L x)_i + x_i - b_i
