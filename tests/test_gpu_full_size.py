@@ -195,7 +195,9 @@ def test_trsv_split_row_blocks_match_oracle_and_unsplit_bits(gpu, ar, st, upper)
     repeatable, and with the SAME summation structure whatever the helpers'
     timing (a second solve gives the same bits)."""
     torch, accblas = gpu
-    n, lda = 16200, 16208
+    # 157 row blocks: 100..124 in 5 parts (owners keep 48 columns), 125..156 in
+    # 8 parts (owners keep 16), the last block ragged
+    n, lda = 20008, 20016
     rng = np.random.default_rng(78)
     full = rng.uniform(-1.0, 1.0, (n, lda)) / np.sqrt(n)
     A = oracle.convert(full.reshape(-1), st)
