@@ -618,42 +618,46 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     const index_type own_row = base + lane;
     const bool own_valid = own_row < n;
     st_type *own_addr = x_data + phys(own_valid ? own_row : n - 1) * x_inc;
-    ar_type own_rhs{};
-    if (own_valid) {
-        own_rhs = static_cast<ar_type>(*own_addr);
-    }
+    const st_type own_raw = *own_addr;  // (clamped address: unconditional)
+    const ar_type own_rhs = own_valid ? static_cast<ar_type>(own_raw) : ar_type{};
 
     // ---- diagonal tile and last panel -> LDS (a wave reads one row) -------
-    // every load of the wave's rows is issued before the first LDS store, so
-    // the staging costs one memory latency, not one per row
+    // Every load of the wave's rows is issued before the first use, so the
+    // staging costs one memory latency, not one per row: the loads are
+    // UNCONDITIONAL (row and column clamped into the matrix; what lies above
+    // the diagonal or beyond n is read and dropped) and stay in the storage
+    // type until all are back - with the loads inside the conditions the
+    // compiler had put a full wait behind each of the 16 (5 us per block).
     if (worker) {
         constexpr int RS = B / Waves;  // rows a wave stages
-        ar_type diag_value[RS];
-        ar_type panel_value[RS];
+        st_type diag_raw[RS];
+        st_type panel_raw[RS];
+        const index_type gc = base + lane;
+        const index_type col = phys(gc < n ? gc : n - 1);
+        const index_type panel_col = phys(block > 0 ? base - B + lane : index_type{0});
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
-            const int r = wave + i * Waves;
-            const index_type gr = base + r;
-            const index_type gc = base + lane;
-            diag_value[i] = ar_type{};
-            if (lane == r) {
-                diag_value[i] = (UnitDiag || gr >= n)
-                                    ? ar_type{1}
-                                    : ar_type(mtx(phys(gr), phys(gc)));
-            } else if (lane < r && gr < n) {
-                diag_value[i] = mtx(phys(gr), phys(gc));
-            }
-            panel_value[i] = ar_type{};
-            if (block > 0 && gr < n) {
-                panel_value[i] = mtx(phys(gr), phys(base - B + lane));
-            }
+            const index_type gr = base + wave + i * Waves;
+            const st_type *row = a_data + phys(gr < n ? gr : n - 1) * lda;
+            diag_raw[i] = row[col];
+            panel_raw[i] = row[panel_col];
         }
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
             const int r = wave + i * Waves;
-            tile[r * ld + lane] = diag_value[i];
+            const index_type gr = base + r;
+            ar_type diag_value{};
+            if (lane == r) {
+                diag_value = (UnitDiag || gr >= n)
+                                 ? ar_type{1}
+                                 : static_cast<ar_type>(diag_raw[i]);
+            } else if (lane < r && gr < n) {
+                diag_value = static_cast<ar_type>(diag_raw[i]);
+            }
+            tile[r * ld + lane] = diag_value;
             if (block > 0) {
-                panel[lane * ld + r] = panel_value[i];
+                panel[lane * ld + r] =
+                    gr < n ? static_cast<ar_type>(panel_raw[i]) : ar_type{};
             }
         }
     }

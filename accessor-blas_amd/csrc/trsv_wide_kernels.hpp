@@ -396,46 +396,60 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     const auto phys = [n](index_type logical) {
         return Upper ? n - 1 - logical : logical;
     };
-    // element (logical row gr, logical column gc), 0 for rows that do not exist
-    const auto entry = [&](index_type gr, index_type gc) -> ar_type {
-        return gr < n ? ar_type(mtx(phys(gr), phys(gc))) : ar_type{};
-    };
     const st_type *a_data = mtx_traits::data(mtx);
     const index_type lda = mtx_traits::stride(mtx);
     st_type *x_data = x_traits::data(x);
     const index_type x_inc = x_traits::stride(x);
 
-    // this block's right-hand side (never written by another workgroup)
-    if (!helper_part && threadIdx.x < R) {
-        const index_type row = base + threadIdx.x;
-        own_lds[threadIdx.x] = row < n ? ar_type(x_data[phys(row) * x_inc])
-                                       : ar_type{};
+    // this block's right-hand side (never written by another workgroup):
+    // loaded ahead of the tiles, used behind them, one wait for all
+    st_type own_raw{};
+    if (!helper_part) {
+        const index_type row = base + threadIdx.x % R;
+        own_raw = x_data[phys(row < n ? row : n - 1) * x_inc];
     }
 
     // ---- stage D00, D11, D10 (a wave reads one tile row per load) ----------
+    // All 24 loads of a lane are UNCONDITIONAL (row and column clamped into
+    // the matrix; what lies above the diagonal or beyond n is read and
+    // dropped) and stay in the storage type until all are back: with the
+    // loads inside the conditions the compiler had put a full wait behind each
+    // of them, 7.5 us per block (and per solve: block 0 starts the chain).
     if (!helper_part) {
         constexpr int RS = H / Waves;  // tile rows a wave stages
-        ar_type d00[RS], d11[RS], d10[RS];
+        st_type raw00[RS], raw11[RS], raw10[RS];
+        const auto clamped = [&](index_type logical) {
+            return phys(logical < n ? logical : n - 1);
+        };
+        const index_type col0 = clamped(base + lane);
+        const index_type col1 = clamped(base + H + lane);
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
             const int r = wave_u + i * Waves;
-            const auto diag_entry = [&](index_type gr, index_type gc) {
+            const st_type *row0 = a_data + clamped(base + r) * lda;
+            const st_type *row1 = a_data + clamped(base + H + r) * lda;
+            raw00[i] = row0[col0];
+            raw11[i] = row1[col1];
+            raw10[i] = row1[col0];
+        }
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            const int r = wave_u + i * Waves;
+            const auto diag_entry = [&](index_type gr, st_type raw) {
                 if (lane == r) {
-                    return (UnitDiag || gr >= n) ? ar_type{1} : entry(gr, gc);
+                    return (UnitDiag || gr >= n) ? ar_type{1} : ar_type(raw);
                 }
-                return lane < r ? entry(gr, gc) : ar_type{};
+                return (lane < r && gr < n) ? ar_type(raw) : ar_type{};
             };
-            d00[i] = diag_entry(base + r, base + lane);
-            d11[i] = diag_entry(base + H + r, base + H + lane);
-            d10[i] = entry(base + H + r, base + lane);
+            tiles[0][r * ld + lane] = diag_entry(base + r, raw00[i]);
+            tiles[1][r * ld + lane] = diag_entry(base + H + r, raw11[i]);
+            tiles[2][r * ld + lane] =
+                base + H + r < n ? ar_type(raw10[i]) : ar_type{};
         }
-#pragma unroll
-        for (int i = 0; i < RS; ++i) {
-            const int r = wave_u + i * Waves;
-            tiles[0][r * ld + lane] = d00[i];
-            tiles[1][r * ld + lane] = d11[i];
-            tiles[2][r * ld + lane] = d10[i];
-        }
+    }
+    if (!helper_part && threadIdx.x < R) {
+        own_lds[threadIdx.x] =
+            base + threadIdx.x < n ? ar_type(own_raw) : ar_type{};
     }
     __syncthreads();
     ACCBLAS_TRSV_WIDE_STAMP(13);  // tiles staged

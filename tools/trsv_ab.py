@@ -11,6 +11,9 @@ REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 sys.path.insert(0, os.path.join(REPO, "accessor-blas_amd", "python"))
 import accblas  # noqa: E402
 
+if os.environ.get("ACCBLAS_LIB_PATH"):  # A/B runs against another build
+    accblas.LIB_PATH = os.environ["ACCBLAS_LIB_PATH"]
+
 F16, F32, F64 = accblas.F16, accblas.F32, accblas.F64
 
 
