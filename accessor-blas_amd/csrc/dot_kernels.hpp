@@ -50,15 +50,19 @@ struct dot_config {
 
 /** Production shapes, chosen by measurement on MI355X (tools/tune_dot.hip,
  *  profiles/r01_tune_dot.txt, profiles/r02_tune_dot.txt): 512-thread
- *  workgroups. Streams beyond the Infinity Cache run fastest when each
- *  workgroup sweeps one contiguous slice with ONE workgroup per CU and 8 load
- *  pairs per lane in flight (256 KB per CU; 2 x 1 GiB fp32: 306 vs 310 us with
- *  two workgroups of 4 pairs, 1 GiB of fp16: 156 vs 159 us and 3 % better in
- *  the median); smaller ones when the whole grid strides together with 2
- *  workgroups per CU and 4 pairs (5.3 vs 5.0 TB/s at 2 x 64 MiB). */
+ *  workgroups. Long streams run fastest when each workgroup sweeps one
+ *  contiguous slice with ONE workgroup per CU and 8 load pairs per lane in
+ *  flight (256 KB per CU; 2 x 1 GiB fp32: 306 vs 310 us with two workgroups of
+ *  4 pairs, 1 GiB of fp16: 156 vs 159 us and 3 % better in the median);
+ *  shorter ones when the whole grid strides together with 2 workgroups per CU
+ *  and 4 pairs. The two cross between 256 and 512 MiB of data
+ *  (profiles/r02_tune_dot_rule.txt, us, strided / contiguous: 128 MiB of fp16 -
+ *  the per-GPU share of config C4 on 8 GPUs - 25.2 / 30.5, 256 MiB 45.6 /
+ *  46.8, 384 MiB 66.4 / 66.2, 512 MiB 85.3 / 81.1, 1 GiB 166 / 164; fp32
+ *  storage 23.9 / 24.9, 43.1 / 44.2, 66.4 / 65.2, 87.3 / 80.7, 172 / 155). */
 using dot_stride_config = dot_config<8, 4, 2, false>;
 using dot_contiguous_config = dot_config<8, 8, 1, true>;
-constexpr index_type dot_contiguous_min_bytes = index_type{1} << 27;
+constexpr index_type dot_contiguous_min_bytes = index_type{3} << 27;  // 384 MiB
 struct dot_auto_config {};
 
 

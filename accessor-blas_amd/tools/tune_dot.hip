@@ -1,5 +1,7 @@
 // Developer tool (not part of the library): times dot kernel shapes on the
 // current GPU, interleaved rounds in one process. Usage: tune_dot [rounds]
+// or: tune_dot rounds n1 n2 ...  (the candidates for the size rule at these
+// lengths, fp16 storage / fp32 arithmetic and fp32 storage / fp64 arithmetic)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -131,6 +133,17 @@ void add_all(P &p, std::vector<entry> &e)
     e.push_back(p.template make<dot_config<8, 4, 4, false>>("w8 u4 b4 stride atomic", true));
 }
 
+template <typename P>
+void add_rule_candidates(P &p, std::vector<entry> &e)
+{
+    e.push_back(p.template make<dot_config<8, 4, 2, false>>("w8 u4 b2 stride (small rule)"));
+    e.push_back(p.template make<dot_config<8, 2, 4, false>>("w8 u2 b4 stride"));
+    e.push_back(p.template make<dot_config<8, 8, 2, true>>("w8 u8 b2 contig"));
+    e.push_back(p.template make<dot_config<8, 4, 2, true>>("w8 u4 b2 contig"));
+    e.push_back(p.template make<dot_config<8, 8, 1, true>>("w8 u8 b1 contig (large rule)"));
+    e.push_back(p.template make<dot_auto_config>("automatic"));
+}
+
 int main(int argc, char **argv)
 {
     const int rounds = argc > 1 ? std::atoi(argv[1]) : 10;
@@ -144,6 +157,20 @@ int main(int argc, char **argv)
     ws.ticket = (unsigned *)(buf + dot_max_partials * 8);
     ws.scalar = buf + dot_max_partials * 8 + dot_ticket_words * 4;
     ws.num_cus = prop.multiProcessorCount;
+    if (argc > 2) {
+        for (int a = 2; a < argc; ++a) {
+            const long n = std::atol(argv[a]);
+            {
+                problem<float, _Float16> p(n, ws);
+                p.sweep("Acc<f32,f16>", rounds, [&](std::vector<entry> &e) { add_rule_candidates(p, e); });
+            }
+            {
+                problem<double, float> p(n / 2, ws);
+                p.sweep("Acc<f64,f32>", rounds, [&](std::vector<entry> &e) { add_rule_candidates(p, e); });
+            }
+        }
+        return 0;
+    }
     {
         problem<double, float> p(1L << 28, ws);
         p.sweep("Acc<f64,f32>", rounds, [&](std::vector<entry> &e) { add_all(p, e); });
