@@ -135,6 +135,36 @@ def test_config_c4_dot_2p28_fp16_storage_fp32_arithmetic(gpu):
     handle.close()
 
 
+@pytest.mark.parametrize("delta", [-8, 0, 3])
+def test_dot_on_both_sides_of_the_size_rule(gpu, delta):
+    """The dot launcher switches from the strided grid to one contiguous slice
+    per workgroup at 384 MiB of data (csrc/dot_kernels.hpp): the result must not
+    care. fp16 storage, fp32 arithmetic, lengths just below, at and just above the
+    switch (the last one with a ragged tail), checked against the sum of 16 chunk
+    dots accumulated in fp64 and for repeatable bits."""
+    torch, accblas = gpu
+    n = (3 << 27) // 4 + delta  # 2 vectors x 2 bytes
+    handle = accblas.Handle()
+    xh = uniform(torch, n, torch.float32, 18).half()
+    yh = uniform(torch, n, torch.float32, 19).half()
+    got = torch.zeros(1, dtype=torch.float32, device="cuda")
+    accblas.acc_dot(handle, F32, F16, F32, n, xh, 1, yh, 1, got)
+    step = (n // 16 + 7) // 8 * 8
+    want = 0.0
+    for lo in range(0, n, step):
+        part = torch.zeros(1, dtype=torch.float64, device="cuda")
+        hi = min(n, lo + step)
+        accblas.acc_dot(handle, F64, F16, F64, hi - lo, xh[lo:], 1, yh[lo:], 1, part)
+        want += float(part)
+    again = torch.zeros(1, dtype=torch.float32, device="cuda")
+    accblas.acc_dot(handle, F32, F16, F32, n, xh, 1, yh, 1, again)
+    torch.cuda.synchronize()
+    scale = (n / 9.0) ** 0.5
+    assert abs(float(got) - want) <= 64 * 2.0 ** -24 * scale
+    assert torch.equal(got, again)
+    handle.close()
+
+
 @pytest.mark.parametrize("upper", [False, True])
 def test_config_c5_trsv_65536_fp32_storage_fp64_arithmetic(gpu, upper):
     """TRSV n = 65536, unit diagonal, St=fp32, Ar=fp64: residual T x - b of sampled
