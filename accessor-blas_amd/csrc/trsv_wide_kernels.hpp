@@ -47,18 +47,6 @@ namespace dev {
 constexpr int trsv_wide_rows = 128;
 constexpr int trsv_wide_waves = 8;
 
-/** Row blocks from `first_block` on are worked on by `parts` workgroups each
- *  (see `kernel::trsv_wide`); parts == 1 switches the splitting off. */
-/** 1: the one poller of a workgroup keeps three staggered probes in flight
- *  (`detail::rolling_poll`, hand-scheduled asm); 0 (default): one probe at a
- *  time. Measured -3 % at n = 8192, 0 to -3 % at 24000, nothing at 65536
- *  (profiles/r02_trsv_rolling_poll_ab.txt): the wait is dominated by the
- *  write-through becoming visible, not by when the next probe arrives, so
- *  the library is built without it. */
-#ifndef ACCBLAS_TRSV_WIDE_ROLLING_POLL
-#define ACCBLAS_TRSV_WIDE_ROLLING_POLL 0
-#endif
-
 /** Block columns next to its diagonal that a workgroup with a long far sweep
  *  keeps for after the panel fold (see `defer_fold` in the kernel). */
 #ifndef ACCBLAS_TRSV_WIDE_DEFERRED
@@ -66,6 +54,8 @@ constexpr int trsv_wide_waves = 8;
 #endif
 constexpr index_type trsv_wide_deferred_columns = ACCBLAS_TRSV_WIDE_DEFERRED;
 
+/** Row blocks from `first_block` on are worked on by `parts` workgroups each
+ *  (see `kernel::trsv_wide`); parts == 1 switches the splitting off. */
 struct trsv_wide_split {
     int first_block;
     int parts;
@@ -131,126 +121,6 @@ struct mma_slot<float> {
     __device__ __forceinline__ static int quad(int within) { return within >> 2; }
     __device__ __forceinline__ static int reg(int within) { return within & 3; }
 };
-
-
-/**
- * Three staggered probes of two one-word granules per lane (`address` and
- * `address` + 512 bytes), rolling: as soon as a probe returns without this
- * solve's tag in all 128 granules it is issued again, so a probe ARRIVES at
- * the memory every third of a round trip - a single probe notices a publication
- * half a round trip late on average and then needs the other half to return.
- * Written as one asm statement because the compiler merges the waits of a
- * C++ loop of this shape into `s_waitcnt vmcnt(0)` at the loop head (all
- * probes then return together; measured: no gain).
- *
- * Returns true with the tagged granules in out0 / out1, false after `rounds`
- * rounds of three probes. On return up to four probe loads are still in
- * flight INTO `slots`: the caller must call `settle_probes(slots)` once it has
- * nothing latency-critical left to do, and before `slots` goes out of use. Must be called by a whole wave
- * (exec all ones: "ready" compares the lane mask with exec).
- */
-__device__ __forceinline__ bool rolling_poll(const granule_word *address,
-                                             std::uint32_t tag,
-                                             unsigned int rounds,
-                                             granule_word &out0,
-                                             granule_word &out1,
-                                             granule_word (&slots)[6])
-{
-    const unsigned long long low = static_cast<unsigned long long>(tag) << 32;
-    const unsigned long long high = low + (1ull << 32);  // tags are < 2^32 - 1
-    unsigned long long mask;
-    unsigned int count;
-    unsigned int ok;
-    asm volatile(
-        "global_load_dwordx2 %[a0], %[addr], off sc1\n\t"
-        "global_load_dwordx2 %[b0], %[addr], off offset:512 sc1\n\t"
-        "s_sleep 5\n\t"
-        "global_load_dwordx2 %[a1], %[addr], off sc1\n\t"
-        "global_load_dwordx2 %[b1], %[addr], off offset:512 sc1\n\t"
-        "s_sleep 5\n\t"
-        "global_load_dwordx2 %[a2], %[addr], off sc1\n\t"
-        "global_load_dwordx2 %[b2], %[addr], off offset:512 sc1\n\t"
-        "s_mov_b32 %[count], 0\n"
-        "rolling_poll_round_%=:\n\t"
-        // ---- probe 0 (the oldest two loads)
-        "s_waitcnt vmcnt(4)\n\t"
-        "v_cmp_ge_u64_e64 %[mask], %[a0], %[low]\n\t"
-        "v_cmp_lt_u64_e64 vcc, %[a0], %[high]\n\t"
-        "s_and_b64 %[mask], %[mask], vcc\n\t"
-        "v_cmp_ge_u64_e64 vcc, %[b0], %[low]\n\t"
-        "s_and_b64 %[mask], %[mask], vcc\n\t"
-        "v_cmp_lt_u64_e64 vcc, %[b0], %[high]\n\t"
-        "s_and_b64 %[mask], %[mask], vcc\n\t"
-        "s_cmp_eq_u64 %[mask], exec\n\t"
-        "s_cbranch_scc1 rolling_poll_hit0_%=\n\t"
-        "global_load_dwordx2 %[a0], %[addr], off sc1\n\t"
-        "global_load_dwordx2 %[b0], %[addr], off offset:512 sc1\n\t"
-        // ---- probe 1
-        "s_waitcnt vmcnt(4)\n\t"
-        "v_cmp_ge_u64_e64 %[mask], %[a1], %[low]\n\t"
-        "v_cmp_lt_u64_e64 vcc, %[a1], %[high]\n\t"
-        "s_and_b64 %[mask], %[mask], vcc\n\t"
-        "v_cmp_ge_u64_e64 vcc, %[b1], %[low]\n\t"
-        "s_and_b64 %[mask], %[mask], vcc\n\t"
-        "v_cmp_lt_u64_e64 vcc, %[b1], %[high]\n\t"
-        "s_and_b64 %[mask], %[mask], vcc\n\t"
-        "s_cmp_eq_u64 %[mask], exec\n\t"
-        "s_cbranch_scc1 rolling_poll_hit1_%=\n\t"
-        "global_load_dwordx2 %[a1], %[addr], off sc1\n\t"
-        "global_load_dwordx2 %[b1], %[addr], off offset:512 sc1\n\t"
-        // ---- probe 2
-        "s_waitcnt vmcnt(4)\n\t"
-        "v_cmp_ge_u64_e64 %[mask], %[a2], %[low]\n\t"
-        "v_cmp_lt_u64_e64 vcc, %[a2], %[high]\n\t"
-        "s_and_b64 %[mask], %[mask], vcc\n\t"
-        "v_cmp_ge_u64_e64 vcc, %[b2], %[low]\n\t"
-        "s_and_b64 %[mask], %[mask], vcc\n\t"
-        "v_cmp_lt_u64_e64 vcc, %[b2], %[high]\n\t"
-        "s_and_b64 %[mask], %[mask], vcc\n\t"
-        "s_cmp_eq_u64 %[mask], exec\n\t"
-        "s_cbranch_scc1 rolling_poll_hit2_%=\n\t"
-        "global_load_dwordx2 %[a2], %[addr], off sc1\n\t"
-        "global_load_dwordx2 %[b2], %[addr], off offset:512 sc1\n\t"
-        "s_add_u32 %[count], %[count], 1\n\t"
-        "s_cmp_lt_u32 %[count], %[rounds]\n\t"
-        "s_cbranch_scc1 rolling_poll_round_%=\n\t"
-        "s_mov_b32 %[ok], 0\n\t"
-        "s_branch rolling_poll_done_%=\n"
-        "rolling_poll_hit0_%=:\n\t"
-        "v_mov_b64 %[o0], %[a0]\n\t"
-        "v_mov_b64 %[o1], %[b0]\n\t"
-        "s_mov_b32 %[ok], 1\n\t"
-        "s_branch rolling_poll_done_%=\n"
-        "rolling_poll_hit1_%=:\n\t"
-        "v_mov_b64 %[o0], %[a1]\n\t"
-        "v_mov_b64 %[o1], %[b1]\n\t"
-        "s_mov_b32 %[ok], 1\n\t"
-        "s_branch rolling_poll_done_%=\n"
-        "rolling_poll_hit2_%=:\n\t"
-        "v_mov_b64 %[o0], %[a2]\n\t"
-        "v_mov_b64 %[o1], %[b2]\n\t"
-        "s_mov_b32 %[ok], 1\n"
-        "rolling_poll_done_%=:"
-        : [a0] "=&v"(slots[0]), [b0] "=&v"(slots[1]), [a1] "=&v"(slots[2]),
-          [b1] "=&v"(slots[3]), [a2] "=&v"(slots[4]), [b2] "=&v"(slots[5]),
-          [o0] "=&v"(out0), [o1] "=&v"(out1), [mask] "=&s"(mask),
-          [count] "=&s"(count), [ok] "=&s"(ok)
-        : [addr] "v"(address), [low] "s"(low), [high] "s"(high),
-          [rounds] "s"(rounds)
-        : "vcc", "scc", "memory");
-    return ok != 0;
-}
-
-/** Waits for the probes `rolling_poll` left in flight and keeps their target
- *  registers allocated up to this point: a register released earlier would be
- *  given to another value and then overwritten by a late probe. Call it after
- *  every `rolling_poll`, once the latency-critical work is done. */
-__device__ __forceinline__ void settle_probes(granule_word (&slots)[6])
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(slots[0]), "v"(slots[1]),
-                 "v"(slots[2]), "v"(slots[3]), "v"(slots[4]), "v"(slots[5])
-                 : "memory");
-}
 
 
 /** Sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (all four end with it). */
@@ -627,21 +497,10 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         io::load(granules, first, raw0);
         io::load(granules, first + H, raw1);
     };
-    granule_word probe_slots[6];  // rolling_poll's probes land here
-    bool probes_in_flight = false;
     const auto poll_finish = [&](index_type first, granule_word (&raw0)[io::words],
                                  granule_word (&raw1)[io::words]) {
         if (__all(io::ready(raw0, epoch) && io::ready(raw1, epoch))) {
             return;  // the early probe already found it
-        }
-        if constexpr (io::words == 1 && ACCBLAS_TRSV_WIDE_ROLLING_POLL) {
-            // staggered probes (hand-scheduled); a miss after ~2^16 rounds
-            // falls through to the bounded loop below
-            probes_in_flight = true;
-            if (detail::rolling_poll(granules + first, epoch, 1u << 16, raw0[0],
-                                     raw1[0], probe_slots)) {
-                return;
-            }
         }
         while (!__all(io::ready(raw0, epoch) && io::ready(raw1, epoch)) &&
                !detail::spin_expired(spins, helper)) {
@@ -854,11 +713,6 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                 acc[k] += static_cast<ar_type>(s.a[k][e]) *
                           xv[Upper ? Vec - 1 - e : e];
             }
-        }
-        if (probes_in_flight) {
-            // the column's x is handed over and used: let the stale probes land
-            detail::settle_probes(probe_slots);
-            probes_in_flight = false;
         }
         // the poller's probe of the next column goes out before its prefetch
         if (cb + 1 == chunk_end_step && cb + 1 < far_end) {
@@ -1079,10 +933,6 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     }
 #endif
 
-    if (probes_in_flight) {
-        detail::settle_probes(probe_slots);
-        probes_in_flight = false;
-    }
     // ---- re-arm the workspace for the next solve (as `kernel::trsv`) -------
     // (`front` was last raised by this block's poller, long before this block
     // counts as finished)
