@@ -1107,11 +1107,7 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
     // hop, two steps are plenty - and that is also what the 256 registers of
     // a lane hold next to W. The bulk of a long sweep runs before W exists
     // (`defer_fold`, helpers of split blocks): as deep as the registers allow.
-#ifdef ACCBLAS_TRSV_WIDE_DEPTH  // experiments (tools/)
-    constexpr int depth = ACCBLAS_TRSV_WIDE_DEPTH;
-#else
     constexpr int depth = sizeof(st_type) == 2 ? 3 : 2;
-#endif
     constexpr int deep_depth = sizeof(st_type) == 2 ? 5 : 4;
     const dim3 grid(trsv_wide_grid(n, split));
     const dim3 block(trsv_wide_waves * wave_size);
