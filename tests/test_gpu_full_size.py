@@ -216,12 +216,13 @@ def test_trsv_24000_matches_reference_shape_both_paths(gpu):
     assert rel_l1(torch, x_vec, x_scalar) <= 1e-6
 
 
-@pytest.mark.parametrize("ar,st", [(F64, F32), (F32, F16), (F64, F64)])
+@pytest.mark.parametrize("ar,st,unit", [(F64, F32, True), (F32, F16, True), (F64, F64, True),
+                                        (F64, F32, False)])
 @pytest.mark.parametrize("upper", [False, True])
-def test_trsv_split_row_blocks_match_oracle_and_unsplit_bits(gpu, ar, st, upper):
+def test_trsv_split_row_blocks_match_oracle_and_unsplit_bits(gpu, ar, st, unit, upper):
     """The 128-row kernel with split row blocks (helpers sum shares of the far
-    columns of the blocks beyond the CU count; here forced from block 100 on, so
-    that n = 16200 exercises it): against the semantic oracle, bit-for-bit
+    columns of the later blocks; here forced from block 100 on, so that n = 20008
+    exercises both split shapes): against the semantic oracle, bit-for-bit
     repeatable, and with the SAME summation structure whatever the helpers'
     timing (a second solve gives the same bits)."""
     torch, accblas = gpu
@@ -230,9 +231,10 @@ def test_trsv_split_row_blocks_match_oracle_and_unsplit_bits(gpu, ar, st, upper)
     n, lda = 20008, 20016
     rng = np.random.default_rng(78)
     full = rng.uniform(-1.0, 1.0, (n, lda)) / np.sqrt(n)
+    full[np.arange(n), np.arange(n)] = rng.uniform(1.0, 2.0, n)
     A = oracle.convert(full.reshape(-1), st)
     b = oracle.convert(rng.uniform(-1.0, 1.0, n), st)
-    want = oracle.exact_trsv(ar, upper, True, n, A, lda, b, 1)
+    want = oracle.exact_trsv(ar, upper, unit, n, A, lda, b, 1)
     dA = torch.from_numpy(A).cuda()
     helper = torch.zeros(2, dtype=torch.int32, device="cuda")
     uplo = accblas.UPPER if upper else accblas.LOWER
@@ -242,7 +244,8 @@ def test_trsv_split_row_blocks_match_oracle_and_unsplit_bits(gpu, ar, st, upper)
         runs = []
         for _ in range(3):
             dx = torch.from_numpy(b).cuda()
-            accblas.acc_trsv(ar, st, uplo, accblas.UNIT, n, dA, lda, dx, 1, helper)
+            accblas.acc_trsv(ar, st, uplo, accblas.UNIT if unit else accblas.NON_UNIT, n, dA, lda,
+                             dx, 1, helper)
             torch.cuda.synchronize()
             assert int(helper[0].item()) & 0xffffffff == 0xffffffff
             runs.append(dx)
