@@ -8,8 +8,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $REPO/bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 tail -1 $OUT/bench.json
+# the SAME command as the bench line above, under the kernel trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o gemv -- \
-    python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs > $OUT/prof_stats.log 2>&1 || exit 2
+    python3 $REPO/bench.py --steps 50 --warmup 5 > $OUT/prof_stats.log 2>&1 || exit 2
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -o gemv -- \
     python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/prof_fetch.log 2>&1 || exit 3
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write -o gemv -- \
