@@ -19,8 +19,12 @@ struct accblas_comm {
     int world_size;
     int rank;
     int device;
-    void *scalar;  // 16-byte device slot: [0, 8) this rank's partial dot in
-                   // `ar`, [8, 16) the reduced one when a cast must follow
+    void *scalar;  // ring of scalar_slots 16-byte device slots, one per dot in
+                   // flight: [0, 8) this rank's partial dot in `ar`, [8, 16)
+                   // the reduced one when a cast must follow
+    unsigned next_slot;    // slot the next accblas_comm_acc_dot takes
+    int group_pending;     // dots recorded in the open group (their
+                           // all-reduces have not been enqueued yet)
     bool always_collective;  // ACCBLAS_COMM_FORCE_COLLECTIVE=1: a world of one
                              // rank still runs the collectives (tests)
 };
@@ -28,6 +32,13 @@ struct accblas_comm {
 
 namespace {
 
+
+// Every accblas_comm_acc_dot takes the next slot of the ring, so several dots
+// may be in flight on one communicator: inside a group the chunk dots run at
+// once while their all-reduces (and casts) wait for the group end, and a
+// second dot must not overwrite what the first all-reduce has yet to read.
+constexpr unsigned scalar_slots = 64;
+constexpr size_t scalar_slot_bytes = 16;
 
 thread_local std::string last_error;
 
@@ -46,6 +57,7 @@ struct pending_cast {
 };
 thread_local int group_depth = 0;
 thread_local std::vector<pending_cast> pending_casts;
+thread_local std::vector<accblas_comm *> group_members;
 
 int fail(int code, const std::string &message)
 {
@@ -125,13 +137,14 @@ int make_comm(accblas_comm **out, ncclComm_t raw, int world_size, int rank,
               int device)
 {
     void *scalar = nullptr;
-    const int status = check_hip(hipMalloc(&scalar, 16), "hipMalloc");
+    const int status = check_hip(
+        hipMalloc(&scalar, scalar_slots * scalar_slot_bytes), "hipMalloc");
     if (status != ACCBLAS_OK) {
         return status;
     }
     const char *force = std::getenv("ACCBLAS_COMM_FORCE_COLLECTIVE");
-    *out = new accblas_comm{raw, world_size, rank, device, scalar,
-                            force != nullptr && force[0] == '1'};
+    *out = new accblas_comm{raw,    world_size, rank, device,
+                            scalar, 0u,         0,    force != nullptr && force[0] == '1'};
     return ACCBLAS_OK;
 }
 
@@ -327,6 +340,10 @@ int accblas_comm_group_end(void)
         }
     }
     pending_casts.clear();
+    for (accblas_comm *member : group_members) {
+        member->group_pending = 0;
+    }
+    group_members.clear();
     return status;
 }
 
@@ -386,13 +403,25 @@ int accblas_comm_acc_dot(accblas_comm *comm, accblas_handle *handle,
         return guard.status();
     }
     const bool collective = comm->world_size > 1 || comm->always_collective;
-    void *const partial = comm->scalar;
-    void *const reduced = static_cast<char *>(comm->scalar) + 8;
     if (!collective) {
         // a world of one rank: the chunk dot writes the result directly
         return check_local(accblas_acc_dot(handle, ar, st, res_t, n_local, x,
                                            incx, y, incy, res, stream));
     }
+    if (group_depth > 0) {
+        if (comm->group_pending >= static_cast<int>(scalar_slots)) {
+            return fail(ACCBLAS_ERR_INVALID_ARGUMENT,
+                        "more than 64 dots on one communicator inside one "
+                        "group: close the group first");
+        }
+        if (comm->group_pending++ == 0) {
+            group_members.push_back(comm);
+        }
+    }
+    char *const slot = static_cast<char *>(comm->scalar) +
+                       (comm->next_slot++ % scalar_slots) * scalar_slot_bytes;
+    void *const partial = slot;
+    void *const reduced = slot + 8;
     // chunk -> device scalar in the ARITHMETIC type (an empty chunk yields 0)
     int status = check_local(accblas_acc_dot(handle, ar, st, ar, n_local, x,
                                              incx, y, incy, partial, stream));

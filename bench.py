@@ -12,6 +12,12 @@ before the timed region.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Both forms work for N > 1: started WITHOUT a launcher (no WORLD_SIZE in the
+environment) the process becomes a parent that touches neither torch nor the
+GPU, starts one child per GPU (`launch_ranks`), relays rank 0's JSON line and
+exits non-zero if any rank fails or the time limit expires (all children are
+killed then). Under torch.distributed.run every process is a rank.
+
 N > 1 ("scaling": "strong"): the SAME n x n problem is split
 into row blocks, rank g owns rows shard_bounds(n, N, g, align=64) of A (n/N
 rows), a replica of x and its slice of res; the timed step is every rank's
@@ -29,7 +35,11 @@ D3); HBM peak 8 TB/s.
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -53,6 +63,76 @@ def parse_args():
     p.add_argument("--no-other-configs", action="store_true",
                    help="skip the untimed measurements of the other BASELINE configs")
     return p.parse_args()
+
+
+def launch_ranks(world, argv, command=None, timeout=None, poll=0.05):
+    """Parent side of `python bench.py --gpus N` without a launcher: starts
+    `world` children of `command` (default: this script) with RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1 and a free MASTER_PORT, each in its own
+    process group. Rank 0's stdout is relayed when every rank has exited with
+    0. The first non-zero exit, or the time limit (ACCBLAS_BENCH_LAUNCH_TIMEOUT
+    seconds, default 1500), kills every child's process group and is the
+    return value (124 for the time limit). The parent never imports torch or
+    touches the GPU, and no process is replaced by another."""
+    if command is None:
+        command = [sys.executable, os.path.abspath(__file__)]
+    if timeout is None:
+        timeout = float(os.environ.get("ACCBLAS_BENCH_LAUNCH_TIMEOUT", "1500"))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    children = []
+    outputs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        out = tempfile.TemporaryFile(mode="w+")
+        outputs.append(out)
+        children.append(subprocess.Popen(list(command) + list(argv), env=env, stdout=out,
+                                         start_new_session=True))
+
+    def kill_all():
+        for child in children:
+            if child.poll() is None:
+                try:
+                    os.killpg(child.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+        for child in children:
+            child.wait()
+
+    status = 0
+    deadline = time.monotonic() + timeout
+    try:
+        while True:
+            codes = [child.poll() for child in children]
+            failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if failed:
+                rank, code = failed[0]
+                print(f"bench.py: rank {rank} of {world} exited with {code}; "
+                      "stopping the other ranks", file=sys.stderr)
+                status = code if code > 0 else 128 - code
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                print(f"bench.py: the {world} ranks did not finish within {timeout:.0f} s; "
+                      "stopping them", file=sys.stderr)
+                status = 124
+                break
+            time.sleep(poll)
+    finally:
+        kill_all()
+    # the result line counts only when every rank finished; what rank 0 had
+    # printed before a failure goes to stderr
+    outputs[0].seek(0)
+    target = sys.stdout if status == 0 else sys.stderr
+    target.write(outputs[0].read())
+    target.flush()
+    for out in outputs:
+        out.close()
+    return status
 
 
 def cpu_baseline(oracle, ar, A_rows, lda, x, res_rows, threads, cpu_reps=12):
@@ -333,6 +413,10 @@ def strong_gemv(local_gemv, rows, dist, steps, warmup, barrier, record=None,
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become the parent of one child per GPU (before torch,
+        # accblas or anything else that could touch the GPU is imported)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     import numpy as np
     import torch
 
@@ -344,9 +428,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus N > 1 must be launched with torch.distributed.run "
-                     "(one process per GPU)")
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     # one process per GPU; ACCBLAS_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box
     # only) lets several ranks share device 0 and use gloo, because RCCL needs

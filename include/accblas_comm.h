@@ -84,8 +84,14 @@ int accblas_shard_bounds(int64_t n, int world_size, int rank, int64_t align,
  * (type res_t) holds the global sum. `handle` as in accblas_acc_dot. Stream
  * order: chunk dot -> all-reduce of ONE element of type `ar` -> cast to res_t
  * (none when res_t == ar: the all-reduce writes `res`). May be called inside a
- * group (see accblas_comm_group_begin). ACCBLAS_COMM_FORCE_COLLECTIVE=1 in the
- * environment makes a world of one rank run the collective as well (tests). */
+ * group (see accblas_comm_group_begin), several times per communicator (e.g.
+ * x.y and x.x batched for CG): every call takes its own 16-byte scalar slot
+ * from a ring of 64, so at most 64 dots per communicator may be recorded in
+ * one group (the 65th returns ACCBLAS_ERR_INVALID_ARGUMENT) and at most 64 may
+ * be in flight on different streams outside a group. Each dot in flight needs
+ * its own `handle` (a handle serialises its calls, accblas.h) unless the calls
+ * share a stream. ACCBLAS_COMM_FORCE_COLLECTIVE=1 in the environment makes a
+ * world of one rank run the collective as well (tests). */
 int accblas_comm_acc_dot(accblas_comm *comm, accblas_handle *handle,
                          accblas_dtype ar, accblas_dtype st,
                          accblas_dtype res_t, int64_t n_local, const void *x,

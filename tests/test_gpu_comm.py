@@ -150,6 +150,61 @@ def test_grouped_dot_casts_after_the_deferred_all_reduce(handle, monkeypatch):
         c.close()
 
 
+def test_several_dots_in_one_group_keep_their_own_scalar_slots(monkeypatch):
+    """x.y and x.x batched in ONE group on one communicator (what a CG step
+    does): inside a group the chunk dots run at once while the all-reduces and
+    casts wait for the group end, so every dot needs its own scalar slot (a
+    shared slot gave the first result the value of the second). More than 64
+    dots in one group are refused."""
+    monkeypatch.setenv("ACCBLAS_COMM_FORCE_COLLECTIVE", "1")
+    torch.cuda.set_device(0)
+    (c,) = comm.Comm.create_all(1)
+    h = accblas.Handle()
+    try:
+        gen = torch.Generator(device="cpu").manual_seed(41)
+        n = 700_001
+        x = (torch.rand(n, generator=gen, dtype=torch.float64) * 2 - 1).float().to(DEV)
+        y = (torch.rand(n, generator=gen, dtype=torch.float64) * 2 - 1).float().to(DEV)
+        want = []
+        for a, b in [(x, y), (x, x), (y, y)]:
+            single = torch.zeros(1, dtype=torch.float32, device=DEV)
+            accblas.acc_dot(h, accblas.F32, accblas.F32, accblas.F32, n, a, 1, b, 1, single)
+            torch.cuda.synchronize()
+            want.append(single.item())
+        assert len(set(want)) == 3
+        for res_dtype, res_t in [(torch.float64, accblas.F64), (torch.float32, accblas.F32)]:
+            results = [torch.full((1,), -1.0, dtype=res_dtype, device=DEV) for _ in range(3)]
+            comm.group_begin()
+            for (a, b), r in zip([(x, y), (x, x), (y, y)], results):
+                c.acc_dot(h, accblas.F32, accblas.F32, res_t, n, a, 1, b, 1, r)
+            comm.group_end()
+            torch.cuda.synchronize()
+            assert [r.item() for r in results] == want
+        # the ring has 64 slots: the 65th dot of one group is refused, and the
+        # group still closes cleanly with the 64 recorded ones
+        results = [torch.zeros(1, dtype=torch.float64, device=DEV) for _ in range(65)]
+        comm.group_begin()
+        try:
+            for r in results[:64]:
+                c.acc_dot(h, accblas.F32, accblas.F32, accblas.F64, n, x, 1, y, 1, r)
+            with pytest.raises(accblas.AccblasError) as info:
+                c.acc_dot(h, accblas.F32, accblas.F32, accblas.F64, n, x, 1, y, 1, results[64])
+            assert info.value.status == -2
+        finally:
+            comm.group_end()
+        torch.cuda.synchronize()
+        assert all(r.item() == want[0] for r in results[:64])
+        # a new group starts with an empty ring again
+        comm.group_begin()
+        c.acc_dot(h, accblas.F32, accblas.F32, accblas.F64, n, x, 1, x, 1, results[64])
+        comm.group_end()
+        torch.cuda.synchronize()
+        assert results[64].item() == want[1]
+    finally:
+        h.close()
+        c.close()
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
 def test_two_gpu_grouped_dot_and_gemv(monkeypatch):
     """One process driving two communicators (accblas_comm_create_all): the
@@ -182,6 +237,36 @@ def test_two_gpu_grouped_dot_and_gemv(monkeypatch):
         scale = float(((xs.double() * ys.double()) ** 2).sum().sqrt())
         assert results[0].item() == results[1].item()
         assert abs(results[0].item() - want) <= 64 * 2.0 ** -24 * scale
+        # row-block GEMV (Acc<fp64, fp32>) with the all-gather of the slices:
+        # every rank ends with the full result, equal to the single-GPU product
+        # bit for bit (row blocks start at multiples of 64 rows)
+        rows, cols = 1024, 3000
+        A = (torch.rand(rows, cols, generator=gen, dtype=torch.float64) * 2 - 1).float()
+        xv = (torch.rand(cols, generator=gen, dtype=torch.float64) * 2 - 1).float()
+        r0 = (torch.rand(rows, generator=gen, dtype=torch.float64) * 2 - 1).float()
+        torch.cuda.set_device(comms[0].device)
+        single = r0.to("cuda:0")
+        accblas.acc_gemv(accblas.F64, accblas.F32, rows, cols, 1.0, A.to("cuda:0"), cols,
+                         xv.to("cuda:0"), 1, 1.0, single, 1)
+        torch.cuda.synchronize(0)
+        fulls = []
+        comm.group_begin()
+        for c in comms:
+            torch.cuda.set_device(c.device)
+            dev = f"cuda:{c.device}"
+            lo, hi = c.shard(rows, 64)
+            assert hi - lo == rows // 2
+            A_l, x_l, r_l = A[lo:hi].contiguous().to(dev), xv.to(dev), r0[lo:hi].to(dev)
+            full = torch.zeros(rows, dtype=torch.float32, device=dev)
+            keep += [A_l, x_l, r_l]
+            fulls.append(full)
+            c.acc_gemv(accblas.F64, accblas.F32, hi - lo, cols, 1.0, A_l, cols, x_l, 1, 1.0,
+                       r_l, 1, res_full=full)
+        comm.group_end()
+        for c in comms:
+            torch.cuda.synchronize(c.device)
+        for full in fulls:
+            assert torch.equal(full.cpu(), single.cpu())
         for h in handles:
             h.close()
     finally:
