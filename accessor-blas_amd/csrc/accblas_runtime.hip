@@ -263,11 +263,8 @@ int accblas_handle_create(accblas_handle **handle)
     if (status != ACCBLAS_OK) {
         return status;
     }
-    constexpr size_t partial_bytes =
-        size_t{accblas::dev::dot_max_partials} * sizeof(double);
-    constexpr size_t ticket_bytes =
-        size_t{accblas::dev::dot_ticket_words} * sizeof(unsigned int);
-    constexpr size_t total_bytes = partial_bytes + ticket_bytes + 2 * 16;
+    constexpr size_t slot_bytes = accblas::dev::dot_slot_bytes;
+    constexpr size_t total_bytes = slot_bytes + 2 * 16;
     void *workspace = nullptr;
     status = check_hip(hipMalloc(&workspace, total_bytes), "hipMalloc");
     if (status != ACCBLAS_OK) {
@@ -284,12 +281,11 @@ int accblas_handle_create(accblas_handle **handle)
     h->dot_mode = ACCBLAS_DOT_DETERMINISTIC;
     h->workspace = workspace;
     auto *bytes = static_cast<char *>(workspace);
-    h->dot_ws.partials = bytes;
-    h->dot_ws.ticket = reinterpret_cast<unsigned int *>(bytes + partial_bytes);
-    h->dot_ws.scalar = bytes + partial_bytes + ticket_bytes;
+    h->dot_ws.slots = reinterpret_cast<accblas::dev::dot_slot_word *>(bytes);
+    h->dot_ws.scalar = bytes + slot_bytes;
     h->dot_ws.num_cus = h->num_cus;
-    h->trsv_helper =
-        reinterpret_cast<std::uint32_t *>(bytes + partial_bytes + ticket_bytes + 16);
+    h->dot_ws.serial = 1;
+    h->trsv_helper = reinterpret_cast<std::uint32_t *>(bytes + slot_bytes + 16);
     *handle = h;
     return ACCBLAS_OK;
 }

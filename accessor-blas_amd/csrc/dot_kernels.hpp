@@ -10,13 +10,18 @@
 //     the storage type, `Unroll` pairs of loads in flight per lane, widen to
 //     the arithmetic type in registers;
 //   * lanes -> wave by shuffle, waves -> workgroup through LDS, then each
-//     workgroup writes its partial to a workspace slot (sc1 store), drains,
-//     and takes a ticket; the workgroup that draws the last ticket adds the
-//     partials in slot order and writes the result already cast to ResType
-//     (so `init_res` and `cast_result` disappear);
-//   * the hand-off follows the guide's agent-scope recipe (sc1 payload,
-//     s_waitcnt vmcnt(0), agent-scope atomic ticket, sc1 reads after the
-//     ticket returned) and is independent of dispatch order and XCD placement.
+//     workgroup hands its partial over as a TAGGED slot ("the data is the
+//     flag": {launch serial, value bits} written with one write-through store,
+//     nothing to drain, no ticket); the last workgroup of the grid collects:
+//     it polls the slots, adds the partials in slot order, writes the result
+//     already cast to ResType (so `init_res` and `cast_result` disappear) and
+//     clears the tags it consumed;
+//   * there is no other state: a slot whose tag is not this launch's serial
+//     (never written, left by an aborted earlier launch, scribbled over) is
+//     simply "not there yet", so nothing has to be re-armed between calls and
+//     nothing a previous call left behind can poison this one. The hand-off
+//     does not depend on dispatch order or XCD placement; only the collector
+//     waits, and only for workgroups that need nothing from it.
 // ACCBLAS_DOT_ATOMIC keeps the reference's behaviour (atomic_add per
 // workgroup) for comparison.
 #pragma once
@@ -32,8 +37,83 @@ namespace dev {
 
 
 constexpr int dot_max_partials = 4096;    // workspace slots in the handle
-constexpr int dot_ticket_shards = 16;     // arrival counters, one 64 B line each
-constexpr int dot_ticket_words = (dot_ticket_shards + 1) * 16;  // + top counter
+using dot_slot_word = unsigned long long;
+constexpr int dot_slot_words = 2;         // {tag, low 32 bits}, {tag, high 32 bits}
+constexpr std::size_t dot_slot_bytes =
+    std::size_t{dot_max_partials} * dot_slot_words * sizeof(dot_slot_word);
+// The collector gives up after this many unsuccessful polls of one slot
+// (seconds; a healthy launch needs microseconds) and returns NaN.
+constexpr unsigned int dot_spin_limit = 1u << 22;
+
+
+namespace detail {
+
+
+/** One partial sum as one (4-byte types) or two (8-byte types) 8-byte words
+ *  {tag : 32 | payload : 32}. Every word is written with a single agent-scope
+ *  (write-through) store, so a reader sees either the old word or the new one,
+ *  never a mix: the tag validates the payload next to it. */
+template <typename T>
+struct dot_slot {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4/8-byte partials only");
+    static constexpr int words = sizeof(T) / 4;
+
+    __device__ __forceinline__ static void publish(dot_slot_word *slots,
+                                                   unsigned int slot, T value,
+                                                   std::uint32_t tag)
+    {
+        const dot_slot_word high = dot_slot_word{tag} << 32;
+        dot_slot_word bits = 0;
+        __builtin_memcpy(&bits, &value, sizeof(T));
+        __hip_atomic_store(slots + dot_slot_words * slot,
+                           high | (bits & 0xffffffffull), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        if (words == 2) {
+            __hip_atomic_store(slots + dot_slot_words * slot + 1,
+                               high | (bits >> 32), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    /** True when the slot carries `tag`; `value` is then its payload. */
+    __device__ __forceinline__ static bool fetch(const dot_slot_word *slots,
+                                                 unsigned int slot,
+                                                 std::uint32_t tag, T &value)
+    {
+        dot_slot_word raw[words];
+#pragma unroll
+        for (int w = 0; w < words; ++w) {
+            raw[w] = __hip_atomic_load(slots + dot_slot_words * slot + w,
+                                       __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int w = 0; w < words; ++w) {
+            ok = ok && (raw[w] >> 32) == tag;
+        }
+        const dot_slot_word bits =
+            (raw[0] & 0xffffffffull) | (words == 2 ? raw[words - 1] << 32 : 0);
+        __builtin_memcpy(&value, &bits, sizeof(T));
+        return ok;
+    }
+
+    /** Clears the tag (a later launch with the same serial - a replayed
+     *  hipGraph - must not take this launch's value for its own). */
+    __device__ __forceinline__ static void clear(dot_slot_word *slots,
+                                                 unsigned int slot)
+    {
+#pragma unroll
+        for (int w = 0; w < words; ++w) {
+            __hip_atomic_store(slots + dot_slot_words * slot + w,
+                               dot_slot_word{0}, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+};
+
+
+}  // namespace detail
 
 
 /** Tuning knobs: waves per workgroup, independent load pairs per lane,
@@ -49,18 +129,20 @@ struct dot_config {
 };
 
 /** Production shapes, chosen by measurement on MI355X (tools/tune_dot.hip,
- *  profiles/r01_tune_dot.txt, profiles/r02_tune_dot.txt): 512-thread
- *  workgroups. Long streams run fastest when each workgroup sweeps one
- *  contiguous slice with ONE workgroup per CU and 8 load pairs per lane in
- *  flight (256 KB per CU; 2 x 1 GiB fp32: 306 vs 310 us with two workgroups of
- *  4 pairs, 1 GiB of fp16: 156 vs 159 us and 3 % better in the median);
- *  shorter ones when the whole grid strides together with 2 workgroups per CU
- *  and 4 pairs. The two cross between 256 and 512 MiB of data
- *  (profiles/r02_tune_dot_rule.txt, us, strided / contiguous: 128 MiB of fp16 -
- *  the per-GPU share of config C4 on 8 GPUs - 25.2 / 30.5, 256 MiB 45.6 /
- *  46.8, 384 MiB 66.4 / 66.2, 512 MiB 85.3 / 81.1, 1 GiB 166 / 164; fp32
- *  storage 23.9 / 24.9, 43.1 / 44.2, 66.4 / 65.2, 87.3 / 80.7, 172 / 155). */
-using dot_stride_config = dot_config<8, 4, 2, false>;
+ *  tools/tune_dot_chunk.hip; profiles/r01_tune_dot.txt, r02_tune_dot*.txt,
+ *  r03_tune_dot_chunk.txt): 512-thread workgroups, ONE per CU. Long streams run
+ *  fastest when each workgroup sweeps one contiguous slice with 8 load pairs
+ *  per lane in flight (256 KB per CU; 2 x 1 GiB fp32: 306 vs 310 us with two
+ *  workgroups of 4 pairs, 1 GiB of fp16: 156 us against 177 us for a strided
+ *  grid); shorter ones when the whole grid strides together with 4 pairs. The
+ *  two cross between 256 and 512 MiB of data (profiles/r02_tune_dot_rule.txt).
+ *  Until round 3 the strided grid had two workgroups per CU; one is as fast
+ *  below 32 MiB and 1-7 % faster from there to 512 MiB with the data coming
+ *  from HBM (rotating buffers, us per launch, two / one per CU: 64 MiB 13.85 /
+ *  12.97, 128 MiB - the per-GPU share of config C4 on 8 GPUs - 22.26 / 22.15
+ *  on one box and 24.87 / 22.13 on another, 256 MiB 41.6 / 40.7, 512 MiB 81.2
+ *  / 78.6), and the collector has half as many slots to gather. */
+using dot_stride_config = dot_config<8, 4, 1, false>;
 using dot_contiguous_config = dot_config<8, 8, 1, true>;
 constexpr index_type dot_contiguous_min_bytes = index_type{3} << 27;  // 384 MiB
 struct dot_auto_config {};
@@ -94,14 +176,16 @@ __global__ __launch_bounds__(64) void cast_result(const InType *in,
  * Vec*sizeof(St) and unit increments (checked by the launcher); Vec == 1 goes
  * through operator() only and works for any increment.
  *
- * Atomic == false: partials[blockIdx.x] + ticket protocol, result written by
- * the last workgroup as ResType. Atomic == true: atomic_add(accum, partial)
- * as `cuda/dot_kernels.cuh:158-160` (accum must be zeroed before).
+ * Atomic == false: tagged slot per workgroup, collected by the last workgroup
+ * of the grid in slot order and written as ResType; `serial` != 0 is the tag
+ * of this launch. Atomic == true: atomic_add(accum, partial) as
+ * `cuda/dot_kernels.cuh:158-160` (accum must be zeroed before).
  */
 template <typename Config, int Vec, bool Atomic, typename XView,
           typename YView, typename ArType, typename ResType>
 __global__ __launch_bounds__(Config::waves *wave_size) void dot(
-    XView x, YView y, ArType *partials, unsigned int *ticket, ResType *res)
+    XView x, YView y, ArType *accum, dot_slot_word *slots,
+    std::uint32_t serial, ResType *res)
 {
     constexpr int Waves = Config::waves;
     constexpr int Unroll = Config::unroll;
@@ -202,60 +286,58 @@ __global__ __launch_bounds__(Config::waves *wave_size) void dot(
     }
 
     __shared__ ar_type scratch[Waves];
-    __shared__ bool is_last;
+    __shared__ ar_type own_sum;
     const ar_type block_sum = block_reduce_sum<Waves>(local, scratch);
 
     if (Atomic) {
         if (threadIdx.x == 0) {
-            atomic_add(partials, block_sum);
+            atomic_add(accum, block_sum);
         }
         return;
     }
 
-    // publish the partial, then take a ticket (guide G16: sc1 payload ->
-    // drain -> agent-scope atomic; the last arriver is told by the value its
-    // add returned). Same-address atomics retire at ~12 ns each, so arrivals
-    // are spread over dot_ticket_shards counters on separate 64 B lines; the
-    // last arriver of a shard then arrives at the top counter.
+    // Hand-off: every workgroup but the last of the grid publishes its partial
+    // as a tagged slot and is done (nothing to drain, no ticket: the tag
+    // arrives with the value). The last workgroup collects.
+    using slot_io = detail::dot_slot<ar_type>;
+    const bool collector = blockIdx.x == gridDim.x - 1;
     if (threadIdx.x == 0) {
-        store_agent(partials + blockIdx.x, block_sum);
-        drain_vmem();
-        const unsigned int shard = blockIdx.x % dot_ticket_shards;
-        const unsigned int shard_size =
-            (gridDim.x - shard + dot_ticket_shards - 1) / dot_ticket_shards;
-        const unsigned int active_shards =
-            gridDim.x < dot_ticket_shards ? gridDim.x : dot_ticket_shards;
-        bool last = false;
-        const unsigned int drawn = __hip_atomic_fetch_add(
-            ticket + 16 * (shard + 1), 1u, __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT);
-        if (drawn == shard_size - 1) {
-            const unsigned int top = __hip_atomic_fetch_add(
-                ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (top == active_shards - 1);
+        if (collector) {
+            own_sum = block_sum;
+        } else {
+            slot_io::publish(slots, blockIdx.x, block_sum, serial);
         }
-        is_last = last;
     }
-    __syncthreads();
-    if (!is_last) {
+    if (!collector) {
         return;
     }
-    // last workgroup: fixed-order sum of the partials (sc1 loads)
+    __syncthreads();  // own_sum written, scratch free again
+    // fixed-order sum of the partials: thread t adds slots t, t + threads, ...
     ar_type total{};
+    bool expired = false;
     for (unsigned int slot = threadIdx.x; slot < gridDim.x;
          slot += block_threads) {
-        total += load_agent(partials + slot);
+        ar_type value = own_sum;
+        if (slot != blockIdx.x) {
+            unsigned int spins = 0;
+            while (!slot_io::fetch(slots, slot, serial, value)) {
+                if (++spins >= dot_spin_limit) {
+                    expired = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            slot_io::clear(slots, slot);
+        }
+        total += value;
     }
-    __syncthreads();  // scratch is reused
     total = block_reduce_sum<Waves>(total, scratch);
+    const bool any_expired = __syncthreads_or(expired);
     if (threadIdx.x == 0) {
-        *res = static_cast<ResType>(total);
-    }
-    // re-arm every counter for the next call on this stream (all arrivals of
-    // this launch have happened: this workgroup drew the last ticket)
-    if (threadIdx.x <= dot_ticket_shards) {
-        __hip_atomic_store(ticket + 16 * threadIdx.x, 0u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        // a wait that gave up (cannot happen on a healthy device) must not
+        // look like a result
+        *res = any_expired ? static_cast<ResType>(__builtin_nanf(""))
+                           : static_cast<ResType>(total);
     }
 }
 
@@ -265,16 +347,25 @@ __global__ __launch_bounds__(Config::waves *wave_size) void dot(
 
 /** Device scratch of a handle that the dot launcher needs. */
 struct dot_workspace {
-    void *partials;          // dot_max_partials * 8 bytes
-    unsigned int *ticket;    // dot_ticket_words words, zero between calls
+    dot_slot_word *slots;    // dot_slot_bytes: one tagged slot per workgroup
     void *scalar;            // 16-byte slot (`get_device_value_ptr`)
     int num_cus;
+    std::uint32_t serial;    // tag of the NEXT launch (host side, never 0)
+
+    /** Tag for one launch; launches that share the slots must not share a
+     *  tag unless one has completed before the other starts (stream order). */
+    std::uint32_t next_serial()
+    {
+        const std::uint32_t tag = serial;
+        serial = serial + 1 == 0 ? 1 : serial + 1;
+        return tag;
+    }
 };
 
 
 template <typename ArType, typename Config, typename ResType, typename XView,
           typename YView>
-hipError_t launch_dot_with(const dot_workspace &ws, bool atomic,
+hipError_t launch_dot_with(dot_workspace &ws, bool atomic,
                            const XView &x, const YView &y, ResType *res,
                            hipStream_t stream)
 {
@@ -310,8 +401,6 @@ hipError_t launch_dot_with(const dot_workspace &ws, bool atomic,
                         (y_traits::stride(y) == 1 || n <= 1) &&
                         is_aligned(x_traits::data(x), 16) &&
                         is_aligned(y_traits::data(y), 16);
-    auto *partials = static_cast<ArType *>(ws.partials);
-
     if (atomic) {
         // reference sequence: init_res -> dot (atomic_add) -> cast_result
         constexpr bool direct = std::is_same<ArType, ResType>::value;
@@ -320,21 +409,23 @@ hipError_t launch_dot_with(const dot_workspace &ws, bool atomic,
         kernel::init_res<<<1, 64, 0, stream>>>(accum);
         if (vec_ok) {
             kernel::dot<Config, vec, true>
-                <<<grid, block, 0, stream>>>(x, y, accum, ws.ticket, res);
+                <<<grid, block, 0, stream>>>(x, y, accum, ws.slots, 0u, res);
         } else {
             kernel::dot<Config, 1, true>
-                <<<grid, block, 0, stream>>>(x, y, accum, ws.ticket, res);
+                <<<grid, block, 0, stream>>>(x, y, accum, ws.slots, 0u, res);
         }
         if (!direct) {
             kernel::cast_result<<<1, 64, 0, stream>>>(accum, res);
         }
     } else {
+        ArType *const unused = nullptr;
+        const std::uint32_t serial = ws.next_serial();
         if (vec_ok) {
             kernel::dot<Config, vec, false>
-                <<<grid, block, 0, stream>>>(x, y, partials, ws.ticket, res);
+                <<<grid, block, 0, stream>>>(x, y, unused, ws.slots, serial, res);
         } else {
             kernel::dot<Config, 1, false>
-                <<<grid, block, 0, stream>>>(x, y, partials, ws.ticket, res);
+                <<<grid, block, 0, stream>>>(x, y, unused, ws.slots, serial, res);
         }
     }
     return hipGetLastError();
@@ -345,7 +436,7 @@ hipError_t launch_dot_with(const dot_workspace &ws, bool atomic,
  *  from the amount of data streamed. */
 template <typename ArType, typename Config = dot_auto_config, typename ResType,
           typename XView, typename YView>
-hipError_t launch_dot(const dot_workspace &ws, bool atomic, const XView &x,
+hipError_t launch_dot(dot_workspace &ws, bool atomic, const XView &x,
                       const YView &y, ResType *res, hipStream_t stream)
 {
     if (!std::is_same<Config, dot_auto_config>::value) {

@@ -440,6 +440,31 @@ using gemv_skew_config = gemv_config<8, 2, 2, 2, true>;
  *  against nine other shapes in profiles/r01_gemv_row_align_ab.txt. */
 using gemv_row_align_config = gemv_config<8, 4, 4, 1, true>;
 
+/** Short rows (at most `gemv_short_row_bytes` of storage per row: the first
+ *  quarter of the reference's sweep, cuda/gemv_benchmark.cu:211-214, and tall
+ *  matrices): the production shape covers 8 KiB of a row per step and would run
+ *  such rows through its ragged end only, with 8 rows per workgroup a small
+ *  matrix leaves half of the CUs without work (n = 1300: 163 workgroups on 256
+ *  CUs). Here two waves share a row and cover 4 KiB per step. Few rows: one row
+ *  per 128-thread workgroup, so that even n = 1100 spreads over all CUs; many
+ *  rows: two groups of two waves, two rows each (x re-used for two rows).
+ *  Both have the SAME summation order per row (it depends on the waves per
+ *  row and the unroll only), so a row block gives the same bits alone as
+ *  inside a taller product. Measured against 20 other shapes and the rocBLAS
+ *  columns in profiles/r03_tune_gemv_small.txt (lda = 24500, us, production
+ *  shape -> this one | rocBLAS): Acc<fp64,fp32> n = 1300 6.80 -> 6.24 | 6.28,
+ *  1900 8.04 -> 6.24 | 6.68, 2200 9.84 -> 6.56 | 8.32, 3000 11.4 -> 9.5 | 13.7,
+ *  4500 21.2 -> 17.2 | 23.7; fp64 2200 13.4 -> 9.5 | 12.8; 24000 x 2000
+ *  Acc<fp64,fp32> 40.1 -> 33.5 | 52.0. Beyond 24 KiB per row the production
+ *  shape is as fast or faster. */
+using gemv_short_config = gemv_config<2, 2, 1, 2, true>;
+using gemv_short_tall_config = gemv_config<4, 2, 2, 2, true>;
+constexpr index_type gemv_short_row_bytes = 24576;
+constexpr index_type gemv_short_max_rows = 4608;  // above: the two-row shape
+static_assert(gemv_short_config::wpr == gemv_short_tall_config::wpr &&
+                  gemv_short_config::unroll == gemv_short_tall_config::unroll,
+              "the two short-row shapes must sum a row in the same order");
+
 /** When the time-skewed sweep is used (option "gemv_skew" of the C ABI). */
 enum class gemv_skew_mode {
     never = 0,
@@ -541,6 +566,26 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
                     kernel::gemv_vec<aligned, vec16, true, false, true>
                         <<<aligned_grid, dim3(aligned::waves * wave_size), 0,
                            stream>>>(alpha, mtx, x, beta, res);
+                } else if (std::is_same<Config, gemv_default_config>::value &&
+                           cols * static_cast<index_type>(sizeof(st_type)) <=
+                               gemv_short_row_bytes) {
+                    // short rows (the choice between the two shapes does not
+                    // change the bits of a row, see gemv_short_config)
+                    if (rows <= gemv_short_max_rows) {
+                        using shape = gemv_short_config;
+                        kernel::gemv_vec<shape, vec16, true, false, false>
+                            <<<dim3(static_cast<unsigned>(
+                                   ceildiv(rows, shape::rows_per_block))),
+                               dim3(shape::waves * wave_size), 0, stream>>>(
+                                alpha, mtx, x, beta, res);
+                    } else {
+                        using shape = gemv_short_tall_config;
+                        kernel::gemv_vec<shape, vec16, true, false, false>
+                            <<<dim3(static_cast<unsigned>(
+                                   ceildiv(rows, shape::rows_per_block))),
+                               dim3(shape::waves * wave_size), 0, stream>>>(
+                                alpha, mtx, x, beta, res);
+                    }
                 } else {
                     kernel::gemv_vec<Config, vec16, true, false, false>
                         <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);

@@ -133,6 +133,65 @@ __device__ __forceinline__ T quad_column_sum(T value)
 }
 
 
+/**
+ * This lane's share of c = inv(T) rhs for a row of row tile `Tile` (rows
+ * 16 Tile .. 16 Tile + 15 of the 128-row block; `row` = this lane's row inside
+ * the block). The row's columns k < 16 (Tile + 1) are split over its four
+ * lanes in runs of eight: lane group fk takes k = 32 m + 8 fk + j, j < 8.
+ *   * Eight columns apart, the four lanes of a row - and with them the 64
+ *     lanes of the wave, whose rows are consecutive - fall on bank pairs
+ *     (8 fk + fi) mod 32, every pair exactly twice: the minimum for 64 8-byte
+ *     reads. With neighbouring columns per lane (k = 16 s + 4 q + fk, the
+ *     layout until round 3) the pairs were (fk + fi) mod 32, up to four lanes
+ *     each, and the eight waves' reads queued in the one LDS: 0.64 us between
+ *     "all far sums in LDS" and "c ready" for the slowest wave, on the chain's
+ *     two-hop path x_{b-2} -> c -> x_b (profiles/r03_trsv_hop_paths.txt).
+ *   * The trip count is a compile-time constant: every LDS read of the row is
+ *     issued before the first FMA needs one.
+ * `x00`, `x11`, `x10` = the inverse's three 64 x 64 tiles, column-major with
+ * leading dimension `ld`. Four partial sums per lane (j mod 4), ascending k.
+ */
+template <int Tile, int ld, typename T>
+__device__ __forceinline__ T inverse_row_times(const T *x00, const T *x11,
+                                               const T *x10, const T *rhs,
+                                               int row, int fk)
+{
+    constexpr int H = 64;
+    constexpr int columns = 16 * (Tile + 1);
+    constexpr int runs = (columns + 31) / 32;
+    T entry[runs][8];
+    T right[runs][8];
+#pragma unroll
+    for (int m = 0; m < runs; ++m) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * m + 8 * fk + j;
+            // (columns beyond the row's last tile exist in LDS - the same
+            // 64-column tile - and are masked out)
+            T value;
+            if (Tile < 4) {
+                value = x00[k * ld + row];
+            } else if (32 * m < H) {
+                value = x10[k * ld + row - H];
+            } else {
+                value = x11[(k - H) * ld + row - H];
+            }
+            entry[m][j] = (32 * m + 31 < columns || k < columns) ? value : T{};
+            right[m][j] = rhs[k];
+        }
+    }
+    T part[4] = {};
+#pragma unroll
+    for (int m = 0; m < runs; ++m) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            part[j & 3] += entry[m][j] * right[m][j];
+        }
+    }
+    return (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+
 }  // namespace detail
 
 
@@ -193,6 +252,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     const int wave_u = __builtin_amdgcn_readfirstlane(wave_id());
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
     unsigned long long diag_stamp[20] = {};
+    unsigned long long diag_poll_issue = 0;   // last probe issued by poll_finish
+    unsigned long long diag_poll_probes = 0;  // probes issued by poll_finish
 #endif
     ACCBLAS_TRSV_WIDE_STAMP(0);  // kernel entry
     const int fi = lane & 15;  // MFMA fragment row (A) / column (B, D)
@@ -504,6 +565,10 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         }
         while (!__all(io::ready(raw0, epoch) && io::ready(raw1, epoch)) &&
                !detail::spin_expired(spins, helper)) {
+#ifdef ACCBLAS_TRSV_WIDE_DIAG
+            diag_poll_issue = wall_clock64();  // issue time of this probe
+            ++diag_poll_probes;
+#endif
             io::load(granules, first, raw0);
             io::load(granules, first + H, raw1);
         }
@@ -835,7 +900,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         }
     }
     ACCBLAS_TRSV_WIDE_STAMP(3);  // this wave's far sums reduced
-    __syncthreads();
+    lds_barrier();  // (what is handed over lives in LDS)
     ACCBLAS_TRSV_WIDE_STAMP(4);  // every wave's far sums in LDS
 
     // the poller's first probe for x_{b-1} travels while c is computed
@@ -848,16 +913,27 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     // a row's columns are split over its four lanes (k = fk mod 4)
     ar_type c_value;
     {
-        ar_type part[4] = {};
-        for (int k4 = 0; k4 < k_end; k4 += 16) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = k4 + q * 4 + fk;
-                part[q] += inv_entry(own_tile_row, k) * rhs_lds[k];
-            }
+        ar_type mine{};
+        const ar_type *x00 = tiles[0], *x11 = tiles[1], *x10 = tiles[2];
+        switch (own_tile) {  // wave-uniform
+#define ACCBLAS_TRSV_WIDE_C_CASE(_tile)                                        \
+    case _tile:                                                                \
+        mine = detail::inverse_row_times<_tile, ld>(x00, x11, x10, rhs_lds,    \
+                                                    own_tile_row, fk);         \
+        break;
+            ACCBLAS_TRSV_WIDE_C_CASE(0)
+            ACCBLAS_TRSV_WIDE_C_CASE(1)
+            ACCBLAS_TRSV_WIDE_C_CASE(2)
+            ACCBLAS_TRSV_WIDE_C_CASE(3)
+            ACCBLAS_TRSV_WIDE_C_CASE(4)
+            ACCBLAS_TRSV_WIDE_C_CASE(5)
+            ACCBLAS_TRSV_WIDE_C_CASE(6)
+            ACCBLAS_TRSV_WIDE_C_CASE(7)
+#undef ACCBLAS_TRSV_WIDE_C_CASE
+        default:
+            break;
         }
-        c_value = detail::quad_column_sum((part[0] + part[1]) +
-                                          (part[2] + part[3]));
+        c_value = detail::quad_column_sum(mine);
     }
 
     ACCBLAS_TRSV_WIDE_STAMP(5);  // c ready
@@ -869,7 +945,15 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             // hands them over through LDS as stored (the lanes widen them),
             // already in the lanes' read order: element 16 tj + within goes
             // to lane group quad(within), position 4 tj + reg(within)
+#ifdef ACCBLAS_TRSV_WIDE_DIAG
+            diag_poll_probes = 0;
+            diag_poll_issue = 0;
+#endif
             poll_finish(base - R + lane, tail_raw0, tail_raw1);
+#ifdef ACCBLAS_TRSV_WIDE_DIAG
+            diag_stamp[18] = diag_poll_probes;  // probes of the hop's own wait
+            diag_stamp[19] = diag_poll_issue;   // issue time of the one that saw it
+#endif
             if (lane == 0) {
                 // blocks 0 .. b-1 are published and visible (just read from
                 // memory): tell the workgroups far behind the front
@@ -884,7 +968,9 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             x_perm[pos + 16] = io::decode(tail_raw1);
             ACCBLAS_TRSV_WIDE_STAMP(6);  // x_{b-1} observed (wave 0 only)
         }
-        __syncthreads();
+        // LDS-only barrier: `__syncthreads()` would make wave 0 wait for its
+        // raise of `front` to come back from memory (0.25 us on the hop)
+        lds_barrier();
         ACCBLAS_TRSV_WIDE_STAMP(7);  // x_{b-1} handed over
         ar_type part[8] = {};
 #pragma unroll

@@ -14,7 +14,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PACKAGE_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))
-LIB_PATH = os.path.join(PACKAGE_ROOT, "lib", "libaccblas_hip.so")
+# (ACCBLAS_LIB_PATH: another build of the same library, for A/B measurements
+# of kernel variants inside one gpurun call; never a different implementation)
+LIB_PATH = os.environ.get("ACCBLAS_LIB_PATH") or \
+    os.path.join(PACKAGE_ROOT, "lib", "libaccblas_hip.so")
 
 F16, F32, F64 = 0, 1, 2
 UPPER, LOWER = 0, 1

@@ -67,10 +67,10 @@ struct problem {
         using st = std::array<gko::acc::size_type, 1>;
         c_range xr(sz{{n, 1}}, (const St *)x, st{{1}});
         c_range yr(sz{{n, 1}}, (const St *)y, st{{1}});
-        auto w = ws;
+        auto *w = &ws;
         auto r = res;
         return {name, [=]() {
-                    CHECK((launch_dot<Ar, Config>(w, atomic, xr, yr, r, nullptr)));
+                    CHECK((launch_dot<Ar, Config>(*w, atomic, xr, yr, r, nullptr)));
                 }};
     }
     template <typename F>
@@ -151,11 +151,11 @@ int main(int argc, char **argv)
     CHECK(hipGetDeviceProperties(&prop, 0));
     dot_workspace ws;
     char *buf;
-    CHECK(hipMalloc(&buf, dot_max_partials * 8 + dot_ticket_words * 4 + 16));
-    CHECK(hipMemset(buf, 0, dot_max_partials * 8 + dot_ticket_words * 4 + 16));
-    ws.partials = buf;
-    ws.ticket = (unsigned *)(buf + dot_max_partials * 8);
-    ws.scalar = buf + dot_max_partials * 8 + dot_ticket_words * 4;
+    CHECK(hipMalloc(&buf, dot_slot_bytes + 16));
+    CHECK(hipMemset(buf, 0, dot_slot_bytes + 16));
+    ws.slots = (dot_slot_word *)buf;
+    ws.scalar = buf + dot_slot_bytes;
+    ws.serial = 1;
     ws.num_cus = prop.multiProcessorCount;
     if (argc > 2) {
         for (int a = 2; a < argc; ++a) {

@@ -201,6 +201,47 @@ int main(int argc, char **argv)
         std::printf("  %4u | %8.2f | %8.2f | %6.2f | %6.2f\n", b, us(b, 0, 0),
                     std::max(us(b, 0, 5), us(b, 7, 5)), us(b, 0, 6) - pub(b - 1), pub(b) - pub(b - 1));
     }
+    // the hop's own wait, probe by probe: when the predecessor's last wave
+    // issued its publishing store, when the probe that saw it was issued, when
+    // it was seen; probes issued while waiting and the mean time per probe
+    std::printf("hop wait: block | c ready -> seen us | probes | us per probe | prev pub -> issue of the "
+                "seeing probe | its round trip | pub spread of prev (min..max over waves)\n");
+    for (unsigned b = 8; b < blocks; b += (blocks > 64 ? blocks / 24 : 1)) {
+        const double c_ready = us(b, 0, 5), seen = us(b, 0, 6);
+        const double probes = double(s[(size_t(b) * 8 + 0) * 20 + 18]);
+        const unsigned long long issue_raw = s[(size_t(b) * 8 + 0) * 20 + 19];
+        const double issue = issue_raw ? (double)(long long)(issue_raw - t0) * 0.01 : c_ready;
+        double pmin = 1e30, pmax = 0;
+        for (int w = 0; w < 8; ++w) { pmin = std::min(pmin, us(b - 1, w, 9)); pmax = std::max(pmax, us(b - 1, w, 9)); }
+        std::printf("  %4u | %6.2f | %4.0f | %5.2f | %6.2f | %5.2f | %5.2f .. %5.2f\n", b, seen - c_ready, probes,
+                    probes > 0 ? (seen - c_ready) / (probes + 1) : 0.0, issue - pmax, seen - issue,
+                    pmin - pub(b - 1), pmax - pub(b - 1));
+    }
+    // every stamp of every block and wave (us since block 0 started; raw 0 = not
+    // taken) for offline analysis: argv[4] = file name
+    if (argc > 4) {
+        std::FILE *f = std::fopen(argv[4], "w");
+        if (f != nullptr) {
+            std::fprintf(f, "block,wave");
+            for (int k = 0; k < 20; ++k) std::fprintf(f, ",s%d", k);
+            std::fprintf(f, "\n");
+            for (unsigned b = 0; b < blocks; ++b) {
+                for (int w = 0; w < 8; ++w) {
+                    std::fprintf(f, "%u,%d", b, w);
+                    for (int k = 0; k < 20; ++k) {
+                        const unsigned long long raw = s[(size_t(b) * 8 + w) * 20 + k];
+                        if (k == 18) {
+                            std::fprintf(f, ",%llu", raw);
+                        } else {
+                            std::fprintf(f, ",%.2f", raw ? (double)(long long)(raw - t0) * 0.01 : -1.0);
+                        }
+                    }
+                    std::fprintf(f, "\n");
+                }
+            }
+            std::fclose(f);
+        }
+    }
     std::uint32_t h[2];
     CHECK(hipMemcpy(h, helper, 8, hipMemcpyDeviceToHost));
     std::printf("helper[0]=%08x\n", h[0]);

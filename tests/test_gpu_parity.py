@@ -66,6 +66,12 @@ GEMV_SHAPES = [
     (3, 70000, 70000, 0),  # few long rows
     (37, 13000, 13004, 0),  # pitch not a multiple of 128 bytes: per-row aligned grids
     (9, 26001, 26004, 0),
+    # the small end of the reference's sweep (top-left blocks of a 24500-wide
+    # matrix): short rows, one row per workgroup
+    (1300, 1300, 24500, 0),
+    (1900, 1900, 24500, 0),
+    (2200, 2200, 24500, 0),
+    (5000, 1500, 1504, 0),  # short rows, many of them: the two-row shape
 ]
 
 
@@ -108,6 +114,27 @@ def test_plain_gemv_equals_accessor_bitwise(gpu, vt, rows, cols, lda, offset):
     torch.cuda.synchronize()
     assert torch.equal(r_plain, r_acc)
     assert not torch.equal(r_plain, to_dev(torch, res0)) or cols == 0
+
+
+@pytest.mark.parametrize("ar,st", [(F64, F32), (F64, F64), (F32, F16)])
+def test_gemv_row_blocks_of_short_rows_keep_their_bits(gpu, ar, st):
+    """Short rows pick one of two workgroup shapes by the NUMBER of rows; a
+    row's summation order is the same in both, so a row block (what one GPU of
+    a sharded GEMV computes) has the bits of the same rows inside the taller
+    product, on either side of the row-count rule."""
+    torch, accblas = gpu
+    rows, cols, lda = 6000, 2000, 2048
+    A = to_dev(torch, make_inputs(41, rows * lda, st))
+    x = to_dev(torch, make_inputs(42, cols, st))
+    res0 = make_inputs(43, rows, st)
+    full = to_dev(torch, res0)
+    accblas.acc_gemv(ar, st, rows, cols, 1.0, A, lda, x, 1, 1.0, full, 1)
+    for lo, hi in [(0, 1000), (1000, 1001), (1024, 5000), (5000, 6000)]:
+        part = to_dev(torch, res0)
+        accblas.acc_gemv(ar, st, hi - lo, cols, 1.0, A[lo * lda:], lda, x, 1, 1.0,
+                         part[lo:], 1)
+        torch.cuda.synchronize()
+        assert torch.equal(part[lo:hi], full[lo:hi]), (lo, hi)
 
 
 def test_gemv_beta_zero_does_not_read_res(gpu):
