@@ -116,10 +116,11 @@ int init_workspace(void *ptr, std::size_t bytes, hipStream_t stream)
     if (status != ACCBLAS_OK) {
         return status;
     }
-    // header = accblas::dev::trsv_state{0, 0, first epoch, 0}; the source of
-    // the copy must outlive the asynchronous copy: static storage
+    // header = a clean `trsv_state`; the source of the copy must outlive the
+    // asynchronous copy: static storage
     static const accblas::dev::trsv_state initial{
-        0u, 0u, accblas::dev::trsv_first_epoch, 0u};
+        accblas::dev::trsv_clean_tickets, 0u, accblas::dev::trsv_first_epoch,
+        0u, 0u};
     return accblas::check_hip(
         hipMemcpyAsync(ptr, &initial, sizeof(initial), hipMemcpyHostToDevice,
                        stream),
@@ -336,6 +337,30 @@ int accblas_acc_trsv(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
 }
 
 
+int accblas_trsv_status(const uint32_t *helper, void *stream, int *expired)
+{
+    if (helper == nullptr || expired == nullptr) {
+        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER,
+                                  "trsv_status: helper or expired is NULL");
+    }
+    int status = accblas::check_hip(
+        hipStreamSynchronize(accblas::as_stream(stream)),
+        "hipStreamSynchronize");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    std::uint32_t word = 0;
+    status = accblas::check_hip(
+        hipMemcpy(&word, helper, sizeof(word), hipMemcpyDeviceToHost),
+        "hipMemcpy(trsv helper)");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    *expired = word == accblas::dev::kernel::detail::trsv_error_word ? 1 : 0;
+    return ACCBLAS_OK;
+}
+
+
 int accblas_trsv_workspace_bytes(accblas_dtype st, int64_t n, size_t *bytes)
 {
     if (bytes == nullptr) {
@@ -407,32 +432,36 @@ int accblas_acc_trsv_ws(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
 
 int accblas_trsv_release_workspace(void *stream)
 {
-    std::lock_guard<std::mutex> lock(workspace_guard);
     int device = 0;
     int status = accblas::check_hip(hipGetDevice(&device), "hipGetDevice");
     if (status != ACCBLAS_OK) {
         return status;
     }
-    const auto found =
-        workspace_cache.find(std::make_pair(device, accblas::as_stream(stream)));
-    if (found == workspace_cache.end()) {
-        return ACCBLAS_OK;
+    // detach the entry under the lock, wait and free outside it: launches on
+    // other streams and devices take the same lock (their leases) and must
+    // not stall for the length of this stream's work
+    workspace_entry detached;
+    {
+        std::lock_guard<std::mutex> lock(workspace_guard);
+        const auto found = workspace_cache.find(
+            std::make_pair(device, accblas::as_stream(stream)));
+        if (found == workspace_cache.end()) {
+            return ACCBLAS_OK;
+        }
+        detached = std::move(found->second);
+        workspace_cache.erase(found);
     }
     // solves still running on these buffers finish first
     status = accblas::check_hip(
         hipStreamSynchronize(accblas::as_stream(stream)),
         "hipStreamSynchronize");
-    if (status != ACCBLAS_OK) {
-        return status;
-    }
-    for (void *old : found->second.retired) {
+    for (void *old : detached.retired) {
         (void)hipFree(old);
     }
-    if (found->second.ptr != nullptr) {
-        (void)hipFree(found->second.ptr);
+    if (detached.ptr != nullptr) {
+        (void)hipFree(detached.ptr);
     }
-    workspace_cache.erase(found);
-    return ACCBLAS_OK;
+    return status;
 }
 
 

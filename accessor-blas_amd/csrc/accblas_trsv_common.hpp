@@ -112,6 +112,8 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
         }
         session = lease.session();
     }
+    // the key the launch's workgroups recognise each other by (`trsv_state`)
+    session.serial = dev::trsv_next_serial();
     const int wide = trsv_wide_option_value();
     const bool use_wide =
         wide != 0 && dev::trsv_wide_applicable(upper, mtx) &&

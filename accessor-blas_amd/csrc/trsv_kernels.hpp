@@ -51,6 +51,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "views.hpp"
 #include "wave_primitives.hpp"
 
@@ -105,20 +107,32 @@ __device__ unsigned long long *trsv_diag_buffer;
 
 
 /**
- * Device-resident state of `kernel::trsv`'s hand-off workspace (its 64-byte
- * header). The workspace is zeroed and this state initialised once, when the
- * buffer is allocated; after that every solve is ONE launch that re-arms the
- * workspace for its successor, with nothing kept on the host (so a captured
- * launch can be replayed from a hipGraph):
+ * Device-resident state of the TRSV hand-off workspace (its header). The
+ * workspace is zeroed and this state initialised once, when the buffer is
+ * allocated; after that every solve is ONE launch that re-arms the workspace
+ * for its successor (so a captured launch can be replayed from a hipGraph):
  *   - granules of a solve carry `epoch` in their tag word (0 = never written,
  *     1 = unused, >= 2 = epochs);
- *   - row blocks are numbered by tickets drawn from `next_ticket`;
- *   - the last workgroup to finish (counted in `finished`) resets both
- *     counters and moves `epoch` on; when the epoch would wrap it zeroes the
- *     granules and starts again at 2.
+ *   - row blocks are numbered by tickets drawn from `tickets`, a 64-bit word
+ *     {key : 32 | next ticket : 32}. Between solves it is {trsv_clean_key, 0}.
+ *     The workgroup that draws ticket 0 of a clean word adds its launch's
+ *     serial number (a kernel argument, different for every launch the host
+ *     enqueues) to the key, so the word reads {serial, t} while the launch
+ *     runs; both keys are good for the launch's own workgroups;
+ *   - the last workgroup to finish (counted in `finished`) puts the word back
+ *     to {trsv_clean_key, 0}, resets the other counters and moves `epoch` on;
+ *     when the epoch would wrap it zeroes the granules and starts again at 2;
+ *   - a word that carries any OTHER key - the serial of a launch that never
+ *     finished, or bytes somebody scribbled over the header - is recognised by
+ *     the first workgroups of the next launch: one of them (a compare-and-swap
+ *     decides) resets `finished` and `front`, moves `epoch` on past whatever
+ *     granules the dead launch left behind, and re-arms the word as
+ *     {serial, 1} (it keeps ticket 0); the others draw again. A launch
+ *     therefore never inherits the state of a predecessor that was aborted or
+ *     whose bounded waits gave up (`detail::draw_ticket`).
  */
 struct trsv_state {
-    unsigned int next_ticket;
+    unsigned long long tickets;
     unsigned int finished;
     unsigned int epoch;
     // `kernel::trsv_wide` only: number of leading 128-row blocks whose
@@ -126,16 +140,36 @@ struct trsv_state {
     // within a solve, 0 between solves). Workgroups far behind the chain's front wait on this
     // one word instead of re-reading the granules they need.
     unsigned int front;
+    unsigned int reserved;
 };
 
 constexpr unsigned int trsv_first_epoch = 2;
+constexpr std::uint32_t trsv_clean_key = 0xC1EA0000u;
+constexpr std::uint32_t trsv_arming_bit = 0x80000000u;
+constexpr unsigned long long trsv_clean_tickets =
+    static_cast<unsigned long long>(trsv_clean_key) << 32;
 
 /** Kernel argument: where the state and the granules live. */
 struct trsv_session {
     trsv_state *state;
     granule_word *granules;
     index_type capacity_words;  // granule words in the workspace
+    std::uint32_t serial;       // this launch's key (never 0 or trsv_clean_key)
 };
+
+/** Host side: a key for the next launch (process-wide, so that launches of
+ *  different streams on a shared workspace differ as well). A hipGraph replays
+ *  its launch with the key it was captured with: fine, every completed solve
+ *  leaves the clean key behind. */
+inline std::uint32_t trsv_next_serial()
+{
+    static std::atomic<std::uint32_t> counter{1};
+    std::uint32_t serial = counter.fetch_add(1, std::memory_order_relaxed);
+    while (serial == 0 || serial == trsv_clean_key) {
+        serial = counter.fetch_add(1, std::memory_order_relaxed);
+    }
+    return serial;
+}
 
 
 namespace kernel {
@@ -172,6 +206,118 @@ __device__ __forceinline__ bool spin_expired(unsigned int &spins,
         return true;
     }
     return false;
+}
+
+/** What a workgroup learns when it joins a solve. */
+struct trsv_ticket {
+    std::uint32_t ticket;  // ~0u: the wait for a usable ticket gave up
+    std::uint32_t epoch;   // tag of this solve's granules
+};
+
+/**
+ * Draws this workgroup's ticket (one thread calls it) and reads the solve's
+ * epoch. The common case is ONE atomic add on `trsv_state::tickets`: a word
+ * that carries the clean key or this launch's serial is in order. Anything
+ * else was left by a launch that did not finish, or is garbage: the callers
+ * then agree through a compare-and-swap on one of them that repairs the state
+ * (see `trsv_state`) while the others wait for the re-armed word. Waits are
+ * bounded like every other wait of the solve (`spin_expired`).
+ */
+__device__ __forceinline__ trsv_ticket draw_ticket(trsv_state *state,
+                                                   std::uint32_t serial,
+                                                   std::uint32_t *helper)
+{
+    using word = unsigned long long;
+    const auto key_of = [](word w) { return static_cast<std::uint32_t>(w >> 32); };
+    const auto low_of = [](word w) { return static_cast<std::uint32_t>(w); };
+    const word armed = static_cast<word>(serial) << 32;
+    trsv_ticket out{~std::uint32_t{0}, 0};
+    const word old = __hip_atomic_fetch_add(&state->tickets, word{1},
+                                            __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+    if (old == trsv_clean_tickets) {
+        // first of a clean state: stamp the launch's serial into the key (it
+        // commutes with the other workgroups' draws; nobody waits for it)
+        __hip_atomic_fetch_add(&state->tickets, armed - trsv_clean_tickets,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out.ticket = 0;
+    } else if ((key_of(old) == trsv_clean_key || key_of(old) == serial) &&
+               low_of(old) < trsv_arming_bit) {
+        out.ticket = low_of(old);
+    } else {
+        // stale or overwritten header
+        unsigned int spins = 0;
+        word seen = old;
+        while (true) {
+            if (key_of(seen) == serial) {
+                if (low_of(seen) < trsv_arming_bit) {
+                    // re-armed by somebody else: draw again
+                    const word again = __hip_atomic_fetch_add(
+                        &state->tickets, word{1}, __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT);
+                    if (key_of(again) == serial &&
+                        low_of(again) < trsv_arming_bit) {
+                        out.ticket = low_of(again);
+                        break;
+                    }
+                    seen = again;
+                    continue;
+                }
+                // being repaired: wait
+                if (spin_expired(spins, helper)) {
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                seen = __hip_atomic_load(&state->tickets, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+            word expected = seen;
+            if (__hip_atomic_compare_exchange_strong(
+                    &state->tickets, &expected, armed | trsv_arming_bit,
+                    __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT)) {
+                // sole repairer: a fresh epoch (granules of the dead launch
+                // must not be taken for this one's), counters at zero, then
+                // the word re-armed with ticket 0 taken
+                std::uint32_t epoch =
+                    __hip_atomic_load(&state->epoch, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT) +
+                    1;
+                epoch = epoch < trsv_first_epoch ? trsv_first_epoch : epoch;
+                __hip_atomic_store(&state->finished, 0u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&state->front, 0u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&state->epoch, epoch, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                drain_vmem();  // performed before the word says "armed"
+                __hip_atomic_store(&state->tickets, armed | word{1},
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                out.ticket = 0;
+                break;
+            }
+            seen = expected;  // what the compare-and-swap found instead
+        }
+    }
+    out.epoch = __hip_atomic_load(&state->epoch, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+    return out;
+}
+
+/** The last workgroup of a solve (one thread calls it): the state as the
+ *  next solve expects it. */
+__device__ __forceinline__ void rearm_state(trsv_state *state,
+                                            std::uint32_t next_epoch)
+{
+    __hip_atomic_store(&state->finished, 0u, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&state->front, 0u, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&state->epoch, next_epoch, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&state->tickets, trsv_clean_tickets, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /** Value of `value` in lane `src_lane` (wave-uniform index), broadcast to all
@@ -578,13 +724,14 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     if (threadIdx.x == 0) {
         // the previous solve on this workspace finished before this kernel
         // started (stream order), so the epoch is stable for the whole solve
-        const unsigned int ticket = __hip_atomic_fetch_add(
-            &session.state->next_ticket, 1u, __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT);
-        shared_epoch = __hip_atomic_load(&session.state->epoch,
-                                         __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-        shared_block = static_cast<std::int32_t>(ticket);
+        const detail::trsv_ticket drawn =
+            detail::draw_ticket(session.state, session.serial, helper);
+        const unsigned int ticket = drawn.ticket;
+        shared_epoch = drawn.epoch;
+        // (a ticket that could not be had - ~0u - is out of range: the
+        // workgroup leaves, helper[0] says why)
+        shared_block = ticket < gridDim.x ? static_cast<std::int32_t>(ticket)
+                                          : std::int32_t{0x3fffffff};
         if (ticket == 0) {
             // `trsv_init` (cuda/trsv_kernels.cuh:38-42) folded into the first
             // block: helper[0] stays ~0 unless a bounded spin expires (nobody
@@ -1054,14 +1201,7 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            __hip_atomic_store(&session.state->next_ticket, 0u,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&session.state->finished, 0u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&session.state->front, 0u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&session.state->epoch, next_epoch,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            detail::rearm_state(session.state, next_epoch);
         }
     }
 }

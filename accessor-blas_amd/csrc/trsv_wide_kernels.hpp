@@ -262,12 +262,13 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     granule_word *const granules = session.granules;
 
     if (threadIdx.x == 0) {
-        const unsigned int ticket = __hip_atomic_fetch_add(
-            &session.state->next_ticket, 1u, __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT);
-        shared_epoch = __hip_atomic_load(&session.state->epoch,
-                                         __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
+        const detail::trsv_ticket drawn =
+            detail::draw_ticket(session.state, session.serial, helper);
+        // (a ticket that could not be had - ~0u - maps to a block beyond the
+        // matrix: the workgroup leaves, helper[0] says why)
+        const unsigned int ticket =
+            drawn.ticket < gridDim.x ? drawn.ticket : 0x3fffffffu;
+        shared_epoch = drawn.epoch;
         // tickets -> (row block, part): blocks below split.first_block have one
         // workgroup; each later block has `parts`, its helpers first and its
         // owner last, so everything a workgroup waits for has a lower ticket
@@ -1043,14 +1044,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            __hip_atomic_store(&session.state->next_ticket, 0u,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&session.state->finished, 0u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&session.state->front, 0u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&session.state->epoch, next_epoch,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            detail::rearm_state(session.state, next_epoch);
         }
     }
 }
@@ -1180,8 +1174,22 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
         return hipSuccess;
     }
     if (split.parts > trsv_wide_max_parts ||
-        split.tail_parts > trsv_wide_max_parts) {
+        split.tail_parts > trsv_wide_max_parts || split.parts < 1 ||
+        split.tail_parts < 1) {
         return hipErrorInvalidValue;
+    }
+    if (split.parts > 1) {
+        // a split block adds its helpers' sums where it folds its panel, which
+        // it only does late (`defer_fold`) when it has at least
+        // 2 x deferred + 1 far columns; and its owner keeps `deferred` columns,
+        // which it must have
+        constexpr int min_first =
+            2 * static_cast<int>(trsv_wide_deferred_columns) + 2;
+        if (split.first_block < min_first ||
+            split.tail_block < split.first_block || split.tail_deferred < 0 ||
+            split.tail_deferred > split.tail_block - 1) {
+            return hipErrorInvalidValue;
+        }
     }
     constexpr int vec16 = 16 / sizeof(st_type);
     // a sweep step of 8-byte storage covers 64 columns: 16 load instructions

@@ -80,8 +80,13 @@ __device__ __forceinline__ T dpp_move(T value)
  * lane instead of Count * log2(Width). Exchanges over lane bits 0..3 are DPP
  * moves (bits 2 and 3 as rotations inside the 16-lane row, which pair every
  * lane with one whose bit differs), bits 4 and 5 `__shfl_xor`. Every lane of a
- * group ends with the group's total of value index `lane & (Count - 1)`;
- * fixed order, so the result is reproducible.
+ * group ends with a total of value index `lane & (Count - 1)`; fixed order,
+ * so the result is reproducible. ONLY lanes [0, Count) of each group hold the
+ * canonical total: the rotations used for lane bits 2 and 3 are one-way moves,
+ * not swaps, so when such a step is a plain all-reduce (Count <= 4 or 8) the
+ * lanes of different quads add the same partial sums in different association
+ * orders and may differ from each other in the last bit. Callers read lanes
+ * [0, Count) (`col_group < NI` in the TRSV kernels).
  */
 template <int Count, int Width, typename T>
 __device__ __forceinline__ T transpose_reduce_sum(const T (&values)[Count],

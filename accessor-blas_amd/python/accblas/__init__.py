@@ -84,6 +84,7 @@ SIGNATURES = {
     "accblas_trsv": (_int, [_int, _int, _int, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "accblas_acc_trsv": (_int, [_int, _int, _int, _int, _i64, _vp, _i64, _vp, _i64,
                                 _vp, _vp]),
+    "accblas_trsv_status": (_int, [_vp, _vp, ctypes.POINTER(_int)]),
     "accblas_trsv_workspace_bytes": (_int, [_int, _i64, ctypes.POINTER(ctypes.c_size_t)]),
     "accblas_trsv_workspace_init": (_int, [_vp, ctypes.c_size_t, _vp]),
     "accblas_trsv_ws": (_int, [_int, _int, _int, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
@@ -277,6 +278,14 @@ def acc_trsv(ar, st, uplo, diag, n, A, lda, x, incx, helper, stream=None):
     """`acc_trsv<ArType, StType>` (`cuda/trsv_kernels.cuh:918-961`)."""
     _check(load().accblas_acc_trsv(ar, st, uplo, diag, n, _ptr(A), lda, _ptr(x), incx,
                                    _ptr(helper), _stream(stream)))
+
+
+def trsv_status(helper, stream=None):
+    """True when an internal wait of the last solve on `helper` gave up
+    (`accblas_trsv_status`; synchronises the stream)."""
+    out = _int()
+    _check(load().accblas_trsv_status(_ptr(helper), _stream(stream), ctypes.byref(out)))
+    return bool(out.value)
 
 
 def _nbytes(buf):

@@ -92,9 +92,9 @@ int main(int argc, char **argv)
     CHECK(hipMemset(granules, 0, ws_bytes));
     trsv_state *state;
     CHECK(hipMalloc(&state, 64));
-    const trsv_state initial{0u, 0u, trsv_first_epoch, 0u};
+    const trsv_state initial{trsv_clean_tickets, 0u, trsv_first_epoch, 0u, 0u};
     CHECK(hipMemcpy(state, &initial, sizeof(initial), hipMemcpyHostToDevice));
-    const trsv_session session{state, granules, index_type(ws_bytes / 8)};
+    const trsv_session session{state, granules, index_type(ws_bytes / 8), 1u};
     fill<<<4096, 256>>>(A, size_t(n) * n, 1, 1.0f / std::sqrt(float(n)));
     fill<<<64, 256>>>(x0, n, 2, 1.0f);
     using sz = std::array<gko::acc::size_type, 2>;

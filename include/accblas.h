@@ -54,8 +54,14 @@ typedef enum accblas_diag {
 
 /* How the per-workgroup dot partials are combined. */
 typedef enum accblas_dot_mode {
-    /* one launch; partials -> workspace; the last workgroup to arrive sums
-     * them in a fixed order: bitwise reproducible (default) */
+    /* one launch; every workgroup hands its partial over as a slot tagged
+     * with the launch's serial number, the last workgroup of the grid collects
+     * the slots and sums them in a fixed order: bitwise reproducible
+     * (default). There are no counters to re-arm: whatever an earlier call -
+     * finished, aborted or scribbled over - left in the handle's scratch
+     * cannot be taken for a partial of this one. Should the collector's wait
+     * ever give up (seconds; it cannot happen on a healthy device) the result
+     * is NaN. */
     ACCBLAS_DOT_DETERMINISTIC = 0,
     /* reference behaviour: zero the result, then one atomic_add per
      * workgroup (cuda/dot_kernels.cuh:114,159; cuda/atomics.cuh:80-103) */
@@ -64,7 +70,8 @@ typedef enum accblas_dot_mode {
 
 /* Replaces `myBlasHandle` (cuda/dot_kernels.cuh:29-65): cached device
  * properties of the current device plus device scratch (dot partials, a
- * 16-byte result slot, the 2-word TRSV helper). */
+ * 16-byte result slot, the 2-word TRSV helper). A handle serialises its dot
+ * calls: use one handle per stream (calls on one stream may share one). */
 typedef struct accblas_handle accblas_handle;
 
 /* ---- diagnostics ------------------------------------------------------- */
@@ -203,8 +210,13 @@ int accblas_acc_dot(accblas_handle *handle, accblas_dtype ar, accblas_dtype st,
  * accblas_trsv_workspace_init, and pass the buffer to any number of solves
  * with n <= n_max and any storage type no wider than `st`. A workspace serves one
  * solve at a time: solves sharing one must be ordered (same stream or events).
- * If a solve is ever aborted mid-kernel, re-initialise the workspace (or
- * release the library-owned one) before using it again. */
+ * Every launch carries a serial number; a launch that finds the workspace
+ * header left by another launch that never finished (aborted, or its bounded
+ * waits gave up), or overwritten, repairs it - counters reset, a fresh epoch
+ * so that stale hand-off words are not taken for new ones - before any row
+ * block proceeds. Re-initialising by hand is never needed. (A hipGraph replays
+ * the serial it was captured with; that is fine after a solve that completed,
+ * which always leaves the header clean.) */
 
 /* `trsv<ValueType>` (cuda/trsv_kernels.cuh:455-488 -> kernels :38-42,
  * :69-235, :263-432). */
@@ -217,6 +229,14 @@ int accblas_trsv(accblas_dtype vt, accblas_uplo uplo, accblas_diag diag,
 int accblas_acc_trsv(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
                      accblas_diag diag, int64_t n, const void *A, int64_t lda,
                      void *x, int64_t incx, uint32_t *helper, void *stream);
+
+/* Did the last solve that used `helper` complete? Synchronises `stream`,
+ * reads helper[0] back and sets *expired to 1 if an internal wait of that
+ * solve gave up (the solution is then invalid), else to 0. Callers need not
+ * know the encoding of helper[0]. A solve that gave up does not poison later
+ * ones: the next launch on the same workspace recognises the unfinished
+ * state and repairs it before it starts (see the workspace notes above). */
+int accblas_trsv_status(const uint32_t *helper, void *stream, int *expired);
 
 /* Bytes of hand-off workspace for solves of up to n unknowns stored as `st`. */
 int accblas_trsv_workspace_bytes(accblas_dtype st, int64_t n, size_t *bytes);
@@ -236,7 +256,10 @@ int accblas_acc_trsv_ws(accblas_dtype ar, accblas_dtype st, accblas_uplo uplo,
 /* Synchronises `stream` and frees every library-owned workspace buffer of
  * (current device, stream), including retired ones. Graphs that captured a
  * solve through accblas_trsv / accblas_acc_trsv on that stream must not be
- * replayed afterwards. */
+ * replayed afterwards. Call it before hipStreamDestroy: the buffers are keyed
+ * by the stream handle and otherwise stay allocated (a later stream that gets
+ * the same handle value would inherit them, which is harmless but not a
+ * release). */
 int accblas_trsv_release_workspace(void *stream);
 
 /* ---- helpers used by the benchmark setup -------------------------------- */

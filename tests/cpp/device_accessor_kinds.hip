@@ -84,10 +84,10 @@ void expect(bool ok, const char *what, double value)
 dot_workspace make_dot_workspace()
 {
     dot_workspace ws{};
-    CHECK(hipMalloc(&ws.partials, dot_max_partials * 8));
-    CHECK(hipMalloc(&ws.ticket, dot_ticket_words * sizeof(unsigned int)));
-    CHECK(hipMemset(ws.ticket, 0, dot_ticket_words * sizeof(unsigned int)));
+    CHECK(hipMalloc(&ws.slots, dot_slot_bytes));
+    CHECK(hipMemset(ws.slots, 0, dot_slot_bytes));
     CHECK(hipMalloc(&ws.scalar, 16));
+    ws.serial = 1;
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     ws.num_cus = prop.multiProcessorCount;
@@ -147,7 +147,7 @@ void row_major_cases(std::default_random_engine &engine)
         double *d_u = to_device(u), *d_v = to_device(v);
         double *d_out{};
         CHECK(hipMalloc(&d_out, sizeof(double)));
-        const auto ws = make_dot_workspace();
+        auto ws = make_dot_workspace();
         c_range uv(size2{{n, 1}}, d_u, stride1{{1}});
         c_range vv(size2{{n, 1}}, d_v, stride1{{1}});
         CHECK((launch_dot<double>(ws, false, uv, vv, d_out, nullptr)));
@@ -180,10 +180,11 @@ void row_major_cases(std::default_random_engine &engine)
         CHECK(hipMemset(granules, 0, ws_bytes));
         trsv_state *state{};
         CHECK(hipMalloc(&state, 64));
-        const trsv_state initial{0u, 0u, trsv_first_epoch, 0u};
+        const trsv_state initial{trsv_clean_tickets, 0u, trsv_first_epoch, 0u, 0u};
         CHECK(hipMemcpy(state, &initial, sizeof(initial), hipMemcpyHostToDevice));
         const trsv_session session{
-            state, granules, static_cast<index_type>(ws_bytes / 8)};
+            state, granules, static_cast<index_type>(ws_bytes / 8),
+            trsv_next_serial()};
         c_range m(size2{{n, n}}, d_t, stride1{{ld}});
         range xv(size2{{n, 1}}, d_b, stride1{{1}});
         CHECK((launch_trsv<double>(false, true, m, xv, helper, session, nullptr)));
@@ -273,7 +274,7 @@ void scaled_cases(std::default_random_engine &engine)
         auto *d_s = to_device(one_scale);
         double *d_out{};
         CHECK(hipMalloc(&d_out, sizeof(double)));
-        const auto ws = make_dot_workspace();
+        auto ws = make_dot_workspace();
         c_sv uv(size2{{n, 1}}, d_u, stride1{{1}}, d_s);
         c_vec vv(size2{{n, 1}}, d_v, stride1{{1}});
         CHECK((launch_dot<double>(ws, false, uv, vv, d_out, nullptr)));

@@ -700,6 +700,97 @@ def test_trsv_workspace_rearms_itself_between_solves(gpu):
         assert err <= 100 * out_tolerance(F64, st), (n, st, option, err)
 
 
+@pytest.mark.parametrize("trsv_kernel", ["rows64", "rows128"], indirect=True)
+def test_trsv_repairs_a_header_left_by_a_dead_solve_or_overwritten(gpu, trsv_kernel):
+    """Every launch carries a serial number; the first workgroups of a launch
+    that find the workspace header in any state but "clean" - a launch that
+    never finished, bytes somebody wrote over it - repair it before a row block
+    proceeds (counters reset, a fresh epoch). Nothing a predecessor left behind
+    may change the result: same bits as on a clean workspace."""
+    torch, accblas = gpu
+    n = 3000
+    A = to_dev(torch, oracle.convert(triangular_system(n, n, False, 430), F32))
+    b = to_dev(torch, make_inputs(431, n, F32))
+    size = accblas.trsv_workspace_bytes(F32, n)
+    workspace = torch.empty(size, dtype=torch.uint8, device="cuda")
+    accblas.trsv_workspace_init(workspace)
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+
+    def solve():
+        x = b.clone()
+        accblas.acc_trsv_ws(F64, F32, accblas.LOWER, accblas.UNIT, n, A, n, x, 1, helper,
+                            workspace)
+        assert not accblas.trsv_status(helper)  # synchronises
+        return x
+
+    clean = solve()
+    want = oracle.exact_trsv(F64, False, True, n, A.cpu().numpy(), n, b.cpu().numpy(), 1)
+    assert oracle.rel_error(want.astype(np.float64), clean.cpu().numpy().astype(np.float64)) \
+        <= 100 * out_tolerance(F64, F32)
+    header = workspace[:32].view(torch.int32)  # tickets lo/hi, finished, epoch, front
+    words = workspace[4096:].view(torch.int64)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    # (1) random bytes over the whole 4 KiB header
+    workspace[:4096] = torch.randint(0, 256, (4096,), dtype=torch.uint8, device="cuda",
+                                     generator=gen)
+    assert torch.equal(solve(), clean)
+    assert torch.equal(solve(), clean)  # and the repaired state is a clean one
+    # (2) a solve that died half way: some tickets drawn under another serial,
+    # some blocks counted as finished, the front somewhere, and - worst - hand-off
+    # words of the CURRENT epoch with wrong values everywhere
+    epoch = int(header[3].item())
+    header[0] = 5
+    header[1] = 0x1234
+    header[2] = 3
+    header[4] = 9
+    words[:] = (epoch << 32) | 0x3F800000  # every x "published" as 1.0f
+    assert torch.equal(solve(), clean)
+    # (3) the word of a launch that is being repaired by nobody (arming bit set
+    # under a serial that is not ours)
+    header[0] = -2147483648  # 0x80000000
+    header[1] = 0x4321
+    assert torch.equal(solve(), clean)
+    # (4) all ones
+    workspace[:4096] = 0xFF
+    assert torch.equal(solve(), clean)
+
+
+def test_dot_ignores_whatever_is_in_its_scratch(gpu):
+    """The dot's hand-off has no counters: a slot counts only if it carries the
+    launch's serial. Garbage over the handle's whole slot area between calls
+    (what a scribbling neighbour or an aborted launch leaves) changes nothing."""
+    torch, accblas = gpu
+    import ctypes
+    lib = accblas.load()
+    h = accblas.Handle()
+    try:
+        n = 3_000_017
+        x = to_dev(torch, make_inputs(71, n, F32))
+        y = to_dev(torch, make_inputs(72, n, F32))
+        res = torch.zeros(1, dtype=torch.float64, device="cuda")
+        accblas.acc_dot(h, F64, F32, F64, n, x, 1, y, 1, res)
+        torch.cuda.synchronize()
+        clean = res.item()
+        scratch = ctypes.c_void_p()
+        assert lib.accblas_handle_device_scratch(h.raw, ctypes.byref(scratch)) == 0
+        slot_bytes = 4096 * 2 * 8  # dot_max_partials x 2 words, in front of the scalar slot
+        rng = np.random.default_rng(9)
+        for fill in ("random", "ones", "zeros"):
+            host = {"random": rng.integers(0, 256, slot_bytes, dtype=np.uint8),
+                    "ones": np.full(slot_bytes, 0xFF, dtype=np.uint8),
+                    "zeros": np.zeros(slot_bytes, dtype=np.uint8)}[fill]
+            assert lib.accblas_memcpy_h2d(ctypes.c_void_p(scratch.value - slot_bytes),
+                                          host.ctypes.data_as(ctypes.c_void_p),
+                                          slot_bytes) == 0
+            for _ in range(2):
+                res.fill_(-1.0)
+                accblas.acc_dot(h, F64, F32, F64, n, x, 1, y, 1, res)
+                torch.cuda.synchronize()
+                assert res.item() == clean, fill
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("src,dst", [(F64, F32), (F64, F16), (F32, F16), (F16, F64),
                                      (F32, F64), (F16, F32)])
 def test_device_convert_is_the_reference_static_cast(gpu, src, dst):
