@@ -294,22 +294,49 @@ __global__ __launch_bounds__(Config::waves *wave_size) void gemv_vec(
         }
     }
 
-    // ---- ragged end: chunk-wise, element-wise for the last partial chunk --
-    for (index_type c = main_cols + lane_off; c < num_cols;
-         c += WPR * wave_cols) {
-        if (c + Vec <= num_cols) {
-            ar_type xa[Vec];
-            load_x<VecX, Vec>(x, x_ptr, c, xa);
+    // ---- ragged end: the whole vectors left of every row in ONE batch of
+    // loads (they are fewer than U per lane: one memory round trip instead of
+    // one per vector - short rows consist of little else, and a row's first
+    // access often pays a page walk on top), then the last partial vector
+    // element-wise. Lanes without a vector load column 0 and add nothing.
+    {
+        const index_type whole_cols = (num_cols / Vec) * Vec;
+        ar_type xa[U][Vec];
+        typename packed<st_type, Vec>::type av[R][U];
+        bool live[U];
 #pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const auto av = load_packed<Vec, Config::nt>(row_ptr[j] + c);
+        for (int u = 0; u < U; ++u) {
+            const index_type c =
+                main_cols + index_type{u} * WPR * wave_cols + lane_off;
+            live[u] = !RowAlign && c + Vec <= whole_cols;
+            const index_type cc = live[u] ? c : 0;
+            // (a row shorter than one vector has no column 0 to fall back on)
+            if (!RowAlign && whole_cols >= Vec) {
+                load_x<VecX, Vec>(x, x_ptr, cc, xa[u]);
 #pragma unroll
-                for (int k = 0; k < Vec; ++k) {
-                    acc[j] += static_cast<ar_type>(av[k]) * xa[k];
+                for (int j = 0; j < R; ++j) {
+                    av[j][u] = load_packed<Vec, Config::nt>(row_ptr[j] + cc);
                 }
             }
-        } else {
-            for (index_type cc = c; cc < num_cols; ++cc) {
+        }
+        if constexpr (!RowAlign) {
+            if (whole_cols >= Vec) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int k = 0; k < Vec; ++k) {
+#pragma unroll
+                        for (int j = 0; j < R; ++j) {
+                            const ar_type term =
+                                static_cast<ar_type>(av[j][u][k]) * xa[u][k];
+                            acc[j] += live[u] ? term : ar_type{};
+                        }
+                    }
+                }
+            }
+            // fewer than Vec columns are left: one lane each
+            const index_type cc = whole_cols + lane;
+            if (wave_in_group == 0 && cc < num_cols) {
                 const ar_type xk = x(cc, 0);
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
@@ -452,11 +479,12 @@ using gemv_row_align_config = gemv_config<8, 4, 4, 1, true>;
  *  row and the unroll only), so a row block gives the same bits alone as
  *  inside a taller product. Measured against 20 other shapes and the rocBLAS
  *  columns in profiles/r03_tune_gemv_small.txt (lda = 24500, us, production
- *  shape -> this one | rocBLAS): Acc<fp64,fp32> n = 1300 6.80 -> 6.24 | 6.28,
- *  1900 8.04 -> 6.24 | 6.68, 2200 9.84 -> 6.56 | 8.32, 3000 11.4 -> 9.5 | 13.7,
- *  4500 21.2 -> 17.2 | 23.7; fp64 2200 13.4 -> 9.5 | 12.8; 24000 x 2000
- *  Acc<fp64,fp32> 40.1 -> 33.5 | 52.0. Beyond 24 KiB per row the production
- *  shape is as fast or faster. */
+ *  shape -> this one | rocBLAS; before the ragged end of the kernel became one
+ *  batch of loads, which closed most of the gap for square matrices):
+ *  Acc<fp64,fp32> n = 1300 6.80 -> 6.24 | 6.28, 1900 8.04 -> 6.24 | 6.68,
+ *  2200 9.84 -> 6.56 | 8.32, 3000 11.4 -> 9.5 | 13.7, 4500 21.2 -> 17.2 | 23.7;
+ *  fp64 2200 13.4 -> 9.5 | 12.8; 24000 x 2000 Acc<fp64,fp32> 40.1 -> 33.5 |
+ *  52.0. Beyond 24 KiB per row the production shape is as fast or faster. */
 using gemv_short_config = gemv_config<2, 2, 1, 2, true>;
 using gemv_short_tall_config = gemv_config<4, 2, 2, 2, true>;
 constexpr index_type gemv_short_row_bytes = 24576;

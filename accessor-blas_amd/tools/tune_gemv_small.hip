@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "gemv_kernels.hpp"
+#include "../../include/accblas.h"
 
 #define CHECK(call)                                                        \
     do {                                                                   \
@@ -48,12 +49,22 @@ struct entry {
 
 static hipEvent_t ev_start, ev_stop;
 
+static bool fresh_events = false;  // as the CLI: new events for every run
+
 double time_us(const std::function<void()> &f, int reps)
 {
     f();
     CHECK(hipDeviceSynchronize());
     double best = 1e30;
     for (int r = 0; r < reps; ++r) {
+        if (fresh_events) {
+            // `CudaTimer` of the reference destroys and re-creates both events
+            // after every measurement (cuda/utils.cuh:144-182)
+            CHECK(hipEventDestroy(ev_start));
+            CHECK(hipEventDestroy(ev_stop));
+            CHECK(hipEventCreate(&ev_start));
+            CHECK(hipEventCreate(&ev_stop));
+        }
         CHECK(hipEventRecord(ev_start, nullptr));
         f();
         CHECK(hipEventRecord(ev_stop, nullptr));
@@ -66,6 +77,9 @@ double time_us(const std::function<void()> &f, int reps)
 }
 
 static bool fine_pass = false;
+// the reference allocates max_size x max_size (2.4 GB of fp32 at 24500): small
+// blocks of a large allocation run slower than the same blocks of a small one
+static bool big_matrix = false;
 
 template <typename Ar, typename St>
 void sweep(const char *title, long lda, int reps, rocblas_handle blas)
@@ -75,7 +89,7 @@ void sweep(const char *title, long lda, int reps, rocblas_handle blas)
     using c_range = gko::acc::range<typename accessor::const_accessor>;
     using sz = std::array<gko::acc::size_type, 2>;
     using st = std::array<gko::acc::size_type, 1>;
-    const long max_n = fine_pass ? 24000 : 6000;
+    const long max_n = big_matrix ? lda : (fine_pass ? 24000 : 6000);
     St *A, *x, *res;
     CHECK(hipMalloc(&A, size_t(max_n) * lda * sizeof(St)));
     CHECK(hipMalloc(&x, lda * sizeof(St)));
@@ -95,7 +109,19 @@ void sweep(const char *title, long lda, int reps, rocblas_handle blas)
                                gemv_skew_mode::never)));                       \
                        }});
     ADD(8, 4, 4, 2)  // production shape
-    if (fine_pass) {
+    if (big_matrix) {
+        ADD(2, 2, 1, 2)
+        ADD(2, 2, 1, 4)
+        ADD(2, 2, 1, 8)
+        ADD(1, 1, 1, 4)
+        ADD(1, 1, 1, 8)
+        ADD(4, 4, 1, 2)
+        ADD(4, 4, 1, 4)
+        ADD(4, 2, 2, 2)
+        ADD(4, 2, 2, 4)
+        ADD(2, 1, 1, 8)
+        ADD(4, 2, 1, 4)
+    } else if (fine_pass) {
         ADD(2, 2, 1, 2)
         ADD(1, 1, 1, 4)
         ADD(4, 4, 1, 1)
@@ -129,6 +155,15 @@ void sweep(const char *title, long lda, int reps, rocblas_handle blas)
     ADD(1, 1, 2, 2)
     }
 #undef ADD
+    // the same call through the C ABI of the library (what the CLI times)
+    entries.push_back({"library", [=](long n, long nc) {
+        const accblas_dtype ar = sizeof(Ar) == 8 ? ACCBLAS_F64 : ACCBLAS_F32;
+        const accblas_dtype st_t = sizeof(St) == 8 ? ACCBLAS_F64 : ACCBLAS_F32;
+        if (accblas_acc_gemv(ar, st_t, n, nc, 1.0, A, lda, x, 1, 1.0, res, 1, nullptr) != 0) {
+            std::fprintf(stderr, "accblas_acc_gemv: %s\n", accblas_last_error_string());
+            std::exit(1);
+        }
+    }});
     entries.push_back({"rocblas", [=](long n, long nc) {
         if (sizeof(St) == 4 && sizeof(Ar) == 4) {
             const float one = 1.0f;
@@ -191,7 +226,9 @@ int main(int argc, char **argv)
 {
     const long lda = argc > 1 ? std::atol(argv[1]) : 24500;
     const int reps = argc > 2 ? std::atoi(argv[2]) : 10;
-    fine_pass = argc > 3;
+    fine_pass = argc > 3 && std::string(argv[3]) == "fine";
+    fresh_events = argc > 3 && std::string(argv[3]) == "fresh";
+    big_matrix = argc > 3 && std::string(argv[3]) == "big";
     CHECK(hipEventCreate(&ev_start));
     CHECK(hipEventCreate(&ev_stop));
     rocblas_handle blas;
