@@ -330,6 +330,53 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank):
     handle.close()
     del x64, y64, xh, yh
 
+    # -- the shape ONE GPU of an 8-GPU run of configs[3] sees: 2^25 fp16 pairs
+    # (128 MiB). On one GPU it is reported beside the full problem: swept over
+    # 6 buffer pairs (768 MiB, three times the Infinity Cache) = sourced from
+    # HBM, and on one pair re-read (cache-resident).
+    if world == 1:
+        chunk, pairs = 1 << 25, 6
+        g = torch.Generator(device=dev)
+        g.manual_seed(300)
+        xc = torch.rand(pairs * chunk, dtype=torch.float32, device=dev, generator=g) \
+            .mul_(2).sub_(1).to(torch.float16)
+        yc = torch.rand(pairs * chunk, dtype=torch.float32, device=dev, generator=g) \
+            .mul_(2).sub_(1).to(torch.float16)
+        hc = accblas.Handle()
+        rc = torch.zeros(1, dtype=torch.float32, device=dev)
+        turn_c = [0]
+
+        def chunk_dot(rotate=True):
+            c = turn_c[0] % pairs if rotate else 0
+            turn_c[0] += 1
+            accblas.acc_dot(hc, F32, F16, F32, chunk, xc[c * chunk:], 1, yc[c * chunk:], 1,
+                            rc, stream)
+
+        t_same = event_time_us(accblas, torch, lambda: chunk_dot(False), stream, reps=10)
+        t_single = event_time_us(accblas, torch, chunk_dot, stream, reps=4 * pairs)
+        t_hbm = float("inf")
+        for _ in range(10):
+            a, b = accblas.Event(), accblas.Event()
+            a.record(stream)
+            for _ in range(4 * pairs):
+                chunk_dot()
+            b.record(stream)
+            b.synchronize()
+            t_hbm = min(t_hbm, a.elapsed_ms(b) * 1e3 / (4 * pairs))
+        out["dot_chunk_2p25_fp16_fp32_one_gpu_share_of_8"] = {
+            "elements": chunk, "bytes": 4 * chunk,
+            "hbm_us_back_to_back": t_hbm,
+            "hbm_GBs": 4.0 * chunk / t_hbm / 1e3,
+            "hbm_frac_of_8TBs": 4.0 * chunk / t_hbm / 1e3 / HBM_PEAK_GBS,
+            "hbm_us_single_launch": t_single,
+            "same_buffers_us_single_launch": t_same,
+            "rotating_buffer_pairs": pairs,
+            "protocol": "min over 10 batches of 24 back-to-back launches sweeping the "
+                        "pairs in turn (per-launch average); single launches: min of "
+                        "event-timed launches, each on the next pair / on one pair"}
+        hc.close()
+        del xc, yc
+
     # -- configs[4]: TRSV n = 65536, lower, unit diagonal, storage fp32,
     # arithmetic fp64; does not shard (replicas only), so rank 0 only
     if rank == 0:
@@ -622,13 +669,23 @@ def main():
         out["multi_gpu"] = multi
     traffic_file = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(traffic_file) and n == 32768 and args.st == "f32" and world == 1:
+        import hashlib
         with open(traffic_file) as f:
             recorded = json.load(f)
-        out["roofline"]["traffic"] = recorded.get("gemv_vec_bytes_per_launch")
-        out["roofline"]["traffic_source"] = (
-            f"replayed from {recorded.get('source')} (builder's rocprofv3 passes on this "
-            "kernel: 2 * FETCH_SIZE + WRITE_SIZE, separate --pmc runs); not measured in "
-            "this run")
+        with open(os.path.join(REPO, "accessor-blas_amd", "csrc", "gemv_kernels.hpp"),
+                  "rb") as f:
+            kernel_hash = hashlib.sha256(f.read()).hexdigest()
+        if recorded.get("gemv_kernels_sha256") == kernel_hash:
+            out["roofline"]["traffic"] = recorded.get("gemv_vec_bytes_per_launch")
+            out["roofline"]["traffic_source"] = (
+                f"replayed from {recorded.get('source')} (builder's rocprofv3 passes on "
+                "this version of the kernel: 2 * FETCH_SIZE + WRITE_SIZE, separate --pmc "
+                "runs); not measured in this run")
+        else:
+            # counters of another version of the kernel say nothing about this one
+            out["roofline"]["traffic_source"] = (
+                "none: csrc/gemv_kernels.hpp changed since the counters in "
+                f"{recorded.get('source')} were taken (re-run tools/gpu_profile.sh)")
 
     # ---- accuracy on rank 0: the reference's metric sum|ref - res| / sum|ref|
     # (gemv_benchmark.cu:101-124) against the fp64 kernel on the unrounded data
@@ -636,6 +693,9 @@ def main():
     got_h = first_result.cpu().numpy()
     out["rel_err_vs_fp64"] = float(np.abs(ref_h - got_h.astype(np.float64)).sum() /
                                    np.abs(ref_h).sum())
+    out["rel_err_inputs"] = ("torch Philox U(-1,1), NOT the reference generator "
+                             "(minstd_rand0(42), which only the CLIs use): compare the "
+                             "magnitude with the published curve, not point for point")
     if world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline leg: the only place the oracle is used (as the
         # baseline and as the checker of a sample of the GPU result)

@@ -14,9 +14,9 @@ REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 BIN = os.path.join(REPO, "accessor-blas_amd", "bin")
 
 
-def run(name, *args):
+def run(name, *args, timeout=600):
     out = subprocess.run([os.path.join(BIN, name), *args], capture_output=True, text=True,
-                         timeout=600)
+                         timeout=timeout)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().split("\n")
     return lines[0].split(";"), [line.split(";") for line in lines[1:]]
@@ -133,6 +133,59 @@ def test_gemv_error_sweep_falls_inside_the_published_bands():
     # rocBLAS fp64 vs the fp64 kernel: same order of magnitude as cuBLAS fp64
     roc = [float(r[header.index("Error ROCBLAS GEMV fp64")]) for r in rows]
     assert max(roc) <= 10 * bands["v100"]["GEMV cuBLAS fp64"]["max"]
+    # the accuracy half of the reference's headline claim (README.md:67-68,
+    # plots/a100_gemv_error_u-1,1.svg at n = 24500: 1.53e-7 vs 3.98e-8): fp64
+    # arithmetic on fp32 storage is several times more accurate than pure fp32
+    assert f32[-1] >= 2.0 * acc[-1]
+    pub_f32 = bands["a100"]["GEMV fp32"]
+    assert 0.5 <= (f32[-1] / acc[-1]) / (pub_f32["at_largest_size"] /
+                                         pub_acc["at_largest_size"]) <= 2.0
+
+
+def test_headline_claim_fp64_arithmetic_at_fp32_storage_speed():
+    """The speed half of the reference's headline claim (README.md:61-76,
+    plots/a100_gemv_flops.svg: 342.4 vs 345.6 vs 178.5 GFLOP/s at the plateau):
+    Acc<fp64, fp32> runs at the speed of the fp32 kernel - the stream of fp32
+    storage is the bound, fp64 arithmetic is free - and about twice as fast as
+    the fp64 kernel. At the reference's own largest size, n = 24500. A
+    regression of the mixed-precision path's speed fails here, not only in the
+    bench line."""
+    header, rows = run("gemv_benchmark", "--only=24500")
+    assert rows[0][0] == "+24500"
+    t = {name: float(rows[0][header.index(name)])
+         for name in ("GEMV fp64", "GEMV fp32", "GEMV Acc<fp64, fp32>")}
+    assert abs(t["GEMV Acc<fp64, fp32>"] / t["GEMV fp32"] - 1.0) <= 0.03, t
+    assert t["GEMV Acc<fp64, fp32>"] <= 0.55 * t["GEMV fp64"], t
+    # and it streams: 4 * (n^2 + 3 n) bytes at >= 75 % of 8 TB/s
+    n = 24500
+    assert 4.0 * (n * n + 3 * n) / (t["GEMV Acc<fp64, fp32>"] * 1e-3) >= 0.75 * 8e12, t
+
+
+def test_dot_error_medians_over_the_whole_published_range():
+    """The published dot sweep runs from 1e6 to 5.35e8 elements
+    (cuda/dot_benchmark.cu:26-27, plots/*_dot_error_median_u-1,1.svg): twelve
+    sizes spread over ALL of it (1e6, 4.9e7, ... 5.29e8; ten re-randomisations
+    of both 5.35e8-element vectors on the host, a few minutes) against the
+    digitised bands."""
+    bands = _published()["dot_error_median"]
+    header, rows = run("dot_benchmark", "--error", "--size=535000000", "--start=1000000",
+                       "--step=48000000", timeout=1500)
+    separator = [i for i, r in enumerate(rows) if r[0].startswith("-----")][0]
+    medians = rows[:separator]
+    assert [int(r[0]) for r in medians] == [1000000 + 48000000 * i for i in range(12)]
+    acc = [float(r[header.index("Error DOT Acc<fp64, fp32>")]) for r in medians]
+    f32 = [float(r[header.index("Error DOT fp32")]) for r in medians]
+    f64acc = [float(r[header.index("Error DOT Acc<fp64, fp64>")]) for r in medians]
+    assert all(v == 0.0 for v in f64acc)  # same bits as the reference column
+    pub_acc = bands["a100"]["DOT Accessor<fp64, fp32>"]
+    assert pub_acc["min"] * 0.5 <= min(acc) and max(acc) <= pub_acc["max"] * 1.5
+    hi32 = max(bands[g]["DOT fp32"]["max"] for g in bands)
+    assert max(f32) <= hi32 * 1.5
+    import statistics
+    assert statistics.median(acc) <= statistics.median(f32)
+    assert statistics.median(acc) <= 3 * pub_acc["median"]
+    roc64 = [float(r[header.index("Error ROCBLAS DOT fp64")]) for r in medians]
+    assert max(roc64) <= 10 * max(bands[g]["DOT cuBLAS fp64"]["max"] for g in bands)
 
 
 def test_dot_error_medians_fall_inside_the_published_bands():

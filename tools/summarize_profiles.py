@@ -21,6 +21,14 @@ def counter_mean(directory, counter, needle):
     return sum(values) / len(values), len(values)
 
 
+def kernel_source_hash():
+    """SHA-256 of the GEMV kernel source the counters were taken with."""
+    import hashlib
+    path = os.path.join(REPO, "accessor-blas_amd", "csrc", "gemv_kernels.hpp")
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(PROF, exist_ok=True)
@@ -49,8 +57,11 @@ def main():
     with open(os.path.join(PROF, f"{tag}_gemv_pmc.json"), "w") as f:
         json.dump(summary, f, indent=1)
     with open(os.path.join(PROF, "traffic.json"), "w") as f:
+        # the counters belong to ONE version of the kernel: bench.py drops the
+        # figure when csrc/gemv_kernels.hpp has changed since
         json.dump({"source": f"profiles/{tag}_gemv_pmc.json",
-                   "gemv_vec_bytes_per_launch": read_bytes + write_bytes}, f, indent=1)
+                   "gemv_vec_bytes_per_launch": read_bytes + write_bytes,
+                   "gemv_kernels_sha256": kernel_source_hash()}, f, indent=1)
     for name in ("dot", "trsv"):
         src = os.path.join(OUT, f"prof_{name}", f"{name}_kernel_stats.csv")
         if os.path.exists(src):
