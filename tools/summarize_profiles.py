@@ -35,6 +35,14 @@ def main():
     shutil.copy(os.path.join(OUT, "prof_stats", "gemv_kernel_stats.csv"),
                 os.path.join(PROF, f"{tag}_gemv_kernel_stats.csv"))
     shutil.copy(os.path.join(OUT, "bench.json"), os.path.join(PROF, f"{tag}_bench.json"))
+    # the line the SAME command printed under the kernel trace: its HIP-event
+    # figures belong beside the trace's own durations (profiles/<tag>_summary.md)
+    traced_log = os.path.join(OUT, "prof_stats.log")
+    if os.path.exists(traced_log):
+        lines = [line for line in open(traced_log) if line.startswith("{")]
+        if lines:
+            with open(os.path.join(PROF, f"{tag}_bench_under_rocprofv3.json"), "w") as f:
+                f.write(lines[-1])
     fetch_kb, n_fetch = counter_mean("prof_fetch", "FETCH_SIZE", "gemv_vec")
     write_kb, n_write = counter_mean("prof_write", "WRITE_SIZE", "gemv_vec")
     # MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
