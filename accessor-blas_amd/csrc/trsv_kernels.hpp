@@ -1212,7 +1212,10 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
 
 /** Helpers a split row block of the 128-row kernel can have (one slot of 128
  *  partial sums each in the workspace). */
-constexpr int trsv_partial_slots = 7;
+#ifndef ACCBLAS_TRSV_PARTIAL_SLOTS
+#define ACCBLAS_TRSV_PARTIAL_SLOTS 15
+#endif
+constexpr int trsv_partial_slots = ACCBLAS_TRSV_PARTIAL_SLOTS;
 
 /** Bytes of hand-off workspace a solve of n unknowns needs behind the state
  *  header: one or two granule words per element of x, then (128-row kernel,

@@ -62,8 +62,12 @@ struct trsv_wide_split {
     int tail_block;  // blocks from here on have `tail_parts` workgroups each
     int tail_parts;  // (smaller shares: the last tickets run almost alone)
     int tail_deferred;  // block columns the owner of a tail block keeps
+    int last_block;  // blocks from here on (>= tail_block): `last_parts` each,
+    int last_parts;  // their owners keep `tail_deferred` columns as well
 };
 constexpr int trsv_wide_max_parts = trsv_partial_slots + 1;
+// helpers' sums an owner takes through LDS at a time
+constexpr int trsv_wide_join_slots = 7;
 
 /** Granule words of the partial-sum area that follows the x granules in the
  *  workspace: (parts - 1) x 128 partial sums per row block, one or two words
@@ -89,7 +93,7 @@ constexpr index_type trsv_wide_partial_offset(index_type n, int words_per_elemen
 // is never built with it.
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
 __device__ unsigned long long *trsv_wide_diag_buffer;
-// one record per workgroup, (block * 16 + part) * 8 words: start, sweep start,
+// one record per workgroup, (block * trsv_wide_max_parts + part) * 8 words: start, sweep start,
 // first time at the front, block column then, end, first column, end column
 __device__ unsigned long long *trsv_wide_diag_workgroups;
 #define ACCBLAS_TRSV_WIDE_STAMP(_slot) diag_stamp[_slot] = wall_clock64()
@@ -241,7 +245,17 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     __shared__ __attribute__((aligned(16))) ar_type tiles[4][H * ld];
     __shared__ ar_type own_lds[R];
     __shared__ ar_type rhs_lds[R];   // own - far correction
-    __shared__ ar_type join_lds[trsv_wide_max_parts - 1][R];  // helpers' sums
+    // helpers' sums: all of a block's at once, or `trsv_wide_join_slots` at a
+    // time. Nothing of this is on a path that matters - the owner joins once -
+    // but the two forms shift the code of the whole kernel: in one process,
+    // builds alternated solve by solve (tools/trsv_lib_ab2.py,
+    // profiles/r03_trsv_tail.txt), 4-byte storage is 0.3-0.9 % faster with the
+    // first form at every size from 8192 to 65536, 2-byte storage 0.6-1.9 %
+    // faster with the second.
+    constexpr bool join_in_rounds = sizeof(st_type) == 2;
+    constexpr int join_rows =
+        join_in_rounds ? trsv_wide_join_slots : trsv_wide_max_parts - 1;
+    __shared__ ar_type join_lds[join_rows][R];
     __shared__ __attribute__((aligned(16))) st_type x_perm[R];    // x_{b-1} in the order the lanes read it
     __shared__ std::int32_t shared_block;
     __shared__ std::int32_t shared_part;  // part of the block, parts - 1 = owner
@@ -278,13 +292,19 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             const std::int32_t beyond = ticket_block - split.first_block;
             const std::int32_t body =
                 (split.tail_block - split.first_block) * split.parts;
+            const std::int32_t tail =
+                (split.last_block - split.tail_block) * split.tail_parts;
             if (beyond < body) {
                 ticket_block = split.first_block + beyond / split.parts;
                 ticket_part = beyond % split.parts;
-            } else {
+            } else if (beyond - body < tail) {
                 ticket_block =
                     split.tail_block + (beyond - body) / split.tail_parts;
                 ticket_part = (beyond - body) % split.tail_parts;
+            } else {
+                ticket_block = split.last_block +
+                               (beyond - body - tail) / split.last_parts;
+                ticket_part = (beyond - body - tail) % split.last_parts;
             }
         }
         shared_block = ticket_block;
@@ -319,7 +339,10 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     // `deferred_columns` block columns and the tail as usual.
     const int parts_here =
         (split.parts > 1 && block >= split.first_block)
-            ? (block >= split.tail_block ? split.tail_parts : split.parts)
+            ? (block >= split.last_block
+                   ? split.last_parts
+                   : (block >= split.tail_block ? split.tail_parts
+                                                : split.parts))
             : 1;
     const int part = shared_part;
     const bool helper_part = part < parts_here - 1;
@@ -832,40 +855,87 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         // round trip for all of them, a few probes' worth of registers), a
         // thread per row adds them up
         if (parts_here > 1) {
-            constexpr int groups = Waves * wave_size / R;
-            constexpr int per_thread =
-                (trsv_wide_max_parts - 1 + groups - 1) / groups;
-            const int row = threadIdx.x % R;
-            const int group = threadIdx.x / R;
-            const index_type slot0 =
-                (block * (trsv_wide_max_parts - 1)) * R + row;
-            granule_word raw[per_thread][io_ar::words];
+            if constexpr (!join_in_rounds) {
+                constexpr int groups = Waves * wave_size / R;
+                constexpr int per_thread =
+                    (trsv_wide_max_parts - 1 + groups - 1) / groups;
+                const int row = threadIdx.x % R;
+                const int group = threadIdx.x / R;
+                const index_type slot0 =
+                    (block * (trsv_wide_max_parts - 1)) * R + row;
+                granule_word raw[per_thread][io_ar::words];
 #pragma unroll
-            for (int j = 0; j < per_thread; ++j) {
-                const int p = group + j * groups;
-                if (p < parts_here - 1) {
-                    io_ar::load(partials, slot0 + p * R, raw[j]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < per_thread; ++j) {
-                const int p = group + j * groups;
-                if (p < parts_here - 1) {
-                    while (!io_ar::ready(raw[j], epoch) &&
-                           !detail::spin_expired(spins, helper)) {
-                        __builtin_amdgcn_s_sleep(4);
+                for (int j = 0; j < per_thread; ++j) {
+                    const int p = group + j * groups;
+                    if (p < parts_here - 1) {
                         io_ar::load(partials, slot0 + p * R, raw[j]);
                     }
-                    join_lds[p][row] = io_ar::decode(raw[j]);
                 }
-            }
-            lds_barrier();
-            if (threadIdx.x < R) {
+#pragma unroll
+                for (int j = 0; j < per_thread; ++j) {
+                    const int p = group + j * groups;
+                    if (p < parts_here - 1) {
+                        while (!io_ar::ready(raw[j], epoch) &&
+                               !detail::spin_expired(spins, helper)) {
+                            __builtin_amdgcn_s_sleep(4);
+                            io_ar::load(partials, slot0 + p * R, raw[j]);
+                        }
+                        join_lds[p][row] = io_ar::decode(raw[j]);
+                    }
+                }
+                lds_barrier();
+                if (threadIdx.x < R) {
+                    ar_type helped{};
+                    for (int p = 0; p < parts_here - 1; ++p) {
+                        helped += join_lds[p][threadIdx.x];
+                    }
+                    own_lds[threadIdx.x] -= helped;
+                }
+            } else {
+                constexpr int groups = Waves * wave_size / R;
+                constexpr int per_thread =
+                    (trsv_wide_join_slots + groups - 1) / groups;
+                const int row = threadIdx.x % R;
+                const int group = threadIdx.x / R;
+                const index_type slot0 =
+                    (block * (trsv_wide_max_parts - 1)) * R + row;
                 ar_type helped{};
-                for (int p = 0; p < parts_here - 1; ++p) {
-                    helped += join_lds[p][threadIdx.x];
+                // (`trsv_wide_join_slots` parts at a time through LDS; the sum
+                // runs over the parts in order across the rounds)
+                for (int p0 = 0; p0 < parts_here - 1; p0 += trsv_wide_join_slots) {
+                    granule_word raw[per_thread][io_ar::words];
+#pragma unroll
+                    for (int j = 0; j < per_thread; ++j) {
+                        const int q = group + j * groups;
+                        if (q < trsv_wide_join_slots && p0 + q < parts_here - 1) {
+                            io_ar::load(partials, slot0 + (p0 + q) * R, raw[j]);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < per_thread; ++j) {
+                        const int q = group + j * groups;
+                        if (q < trsv_wide_join_slots && p0 + q < parts_here - 1) {
+                            while (!io_ar::ready(raw[j], epoch) &&
+                                   !detail::spin_expired(spins, helper)) {
+                                __builtin_amdgcn_s_sleep(4);
+                                io_ar::load(partials, slot0 + (p0 + q) * R, raw[j]);
+                            }
+                            join_lds[q][row] = io_ar::decode(raw[j]);
+                        }
+                    }
+                    lds_barrier();
+                    if (threadIdx.x < R) {
+                        for (int q = 0; q < trsv_wide_join_slots &&
+                                        p0 + q < parts_here - 1;
+                             ++q) {
+                            helped += join_lds[q][threadIdx.x];
+                        }
+                    }
+                    lds_barrier();
                 }
-                own_lds[threadIdx.x] -= helped;
+                if (threadIdx.x < R) {
+                    own_lds[threadIdx.x] -= helped;
+                }
             }
         }
     };
@@ -1008,7 +1078,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     }
     if (threadIdx.x == 0 && trsv_wide_diag_workgroups != nullptr) {
         unsigned long long *record =
-            trsv_wide_diag_workgroups + (block * 16 + part) * 8;
+            trsv_wide_diag_workgroups +
+            (block * trsv_wide_max_parts + part) * 8;
         record[0] = diag_stamp[0];
         record[1] = helper_part ? diag_stamp[12] : diag_stamp[1];
         record[2] = diag_stamp[16];
@@ -1092,6 +1163,12 @@ bool trsv_wide_applicable(bool upper, const MtxView &mtx)
 #ifndef ACCBLAS_TRSV_WIDE_TAIL_BLOCKS
 #define ACCBLAS_TRSV_WIDE_TAIL_BLOCKS 32
 #endif
+#ifndef ACCBLAS_TRSV_WIDE_MAX_TAIL_BLOCKS
+#define ACCBLAS_TRSV_WIDE_MAX_TAIL_BLOCKS 96
+#endif
+#ifndef ACCBLAS_TRSV_WIDE_LAST_PARTS
+#define ACCBLAS_TRSV_WIDE_LAST_PARTS 16
+#endif
 #ifndef ACCBLAS_TRSV_WIDE_TAIL_DEFERRED
 #define ACCBLAS_TRSV_WIDE_TAIL_DEFERRED 16
 #endif
@@ -1109,7 +1186,16 @@ bool trsv_wide_applicable(bool upper, const MtxView &mtx)
  *  us, unsplit -> 5 parts -> 5 parts + 8 for the last 64 blocks):
  *  n = 40000: 845-863 -> 747-785 -> 748-778; n = 65536: 1554 -> 1563-1608 ->
  *  1496-1500; the other tail shapes tried since are within 2 % of each other
- *  (profiles/r02_trsv_split_first.txt). */
+ *  (profiles/r02_trsv_split_first.txt).
+ *  Round 3: the solve's drain - the time between the last ticket and the last
+ *  publication, CUs going idle one by one - is as long as the last shares take
+ *  at what ONE workgroup streams (39 GB/s: 4.5 MB shares, 110-130 us at
+ *  n = 65536, profiles/r03_trsv_tail.txt). Large solves therefore get a longer
+ *  tail (all split blocks but the first 32, up to
+ *  ACCBLAS_TRSV_WIDE_MAX_TAIL_BLOCKS) whose last third has
+ *  ACCBLAS_TRSV_WIDE_LAST_PARTS workgroups per block: 65536 -1.5...-3 %, 57344
+ *  -1...-1.7 %, 40000-49152 unchanged within +-0.3 %; 24 or 32 parts for the
+ *  last blocks are no better than 16 (every part costs its owner a wait). */
 inline trsv_wide_split trsv_wide_split_for(index_type n, int num_cus,
                                            int split_from = 0)
 {
@@ -1130,16 +1216,30 @@ inline trsv_wide_split trsv_wide_split_for(index_type n, int num_cus,
     const int wanted = split_from > 0 ? split_from : num_cus + whole;
     const int first = wanted > min_first ? wanted : min_first;
     if (ACCBLAS_TRSV_WIDE_PARTS > 1 && blocks > first) {
-        const int tail_blocks = ACCBLAS_TRSV_WIDE_TAIL_BLOCKS < blocks - first
-                                    ? ACCBLAS_TRSV_WIDE_TAIL_BLOCKS
-                                    : blocks - first;
-        return trsv_wide_split{first, ACCBLAS_TRSV_WIDE_PARTS,
+        const int split_blocks = blocks - first;
+        int tail_blocks = split_blocks - ACCBLAS_TRSV_WIDE_TAIL_BLOCKS;
+        tail_blocks = tail_blocks > ACCBLAS_TRSV_WIDE_MAX_TAIL_BLOCKS
+                          ? ACCBLAS_TRSV_WIDE_MAX_TAIL_BLOCKS
+                          : tail_blocks;
+        tail_blocks = tail_blocks < ACCBLAS_TRSV_WIDE_TAIL_BLOCKS
+                          ? ACCBLAS_TRSV_WIDE_TAIL_BLOCKS
+                          : tail_blocks;
+        tail_blocks = tail_blocks < split_blocks ? tail_blocks : split_blocks;
+        const int last_blocks =
+            ACCBLAS_TRSV_WIDE_LAST_PARTS > ACCBLAS_TRSV_WIDE_TAIL_PARTS
+                ? tail_blocks / 3
+                : 0;
+        return trsv_wide_split{first,
+                               ACCBLAS_TRSV_WIDE_PARTS,
                                blocks - tail_blocks,
                                ACCBLAS_TRSV_WIDE_TAIL_PARTS,
-                               ACCBLAS_TRSV_WIDE_TAIL_DEFERRED};
+                               ACCBLAS_TRSV_WIDE_TAIL_DEFERRED,
+                               blocks - last_blocks,
+                               last_blocks > 0 ? ACCBLAS_TRSV_WIDE_LAST_PARTS : 1};
     }
     return trsv_wide_split{blocks, 1, blocks, 1,
-                           static_cast<int>(trsv_wide_deferred_columns)};
+                           static_cast<int>(trsv_wide_deferred_columns), blocks,
+                           1};
 }
 
 /** Workgroups a solve launches under `split`. */
@@ -1148,7 +1248,8 @@ inline unsigned trsv_wide_grid(index_type n, const trsv_wide_split &split)
     const index_type blocks = ceildiv(n, index_type{trsv_wide_rows});
     return static_cast<unsigned>(
         split.first_block + (split.tail_block - split.first_block) * split.parts +
-        (blocks - split.tail_block) * split.tail_parts);
+        (split.last_block - split.tail_block) * split.tail_parts +
+        (blocks - split.last_block) * split.last_parts);
 }
 
 /** The 128-row kernel under an explicit `split` (tools; the library goes
@@ -1167,7 +1268,8 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
                       view_traits<XView>::is_pointer_view,
                   "reduced_row_major / row_major / plain views only");
     static_assert(ACCBLAS_TRSV_WIDE_PARTS <= trsv_wide_max_parts &&
-                      ACCBLAS_TRSV_WIDE_TAIL_PARTS <= trsv_wide_max_parts,
+                      ACCBLAS_TRSV_WIDE_TAIL_PARTS <= trsv_wide_max_parts &&
+                      ACCBLAS_TRSV_WIDE_LAST_PARTS <= trsv_wide_max_parts,
                   "too many parts");
     const index_type n = mtx.length(0);
     if (n <= 0) {
@@ -1175,7 +1277,10 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
     }
     if (split.parts > trsv_wide_max_parts ||
         split.tail_parts > trsv_wide_max_parts || split.parts < 1 ||
-        split.tail_parts < 1) {
+        split.tail_parts < 1 || split.last_parts > trsv_wide_max_parts ||
+        split.last_parts < 1 ||
+        split.last_block > ceildiv(n, index_type{trsv_wide_rows}) ||
+        split.last_block < split.tail_block) {
         return hipErrorInvalidValue;
     }
     if (split.parts > 1) {

@@ -1,7 +1,7 @@
 // Developer tool (not part of the library): the 128-row TRSV kernel under
 // several row-block splits, alternated in ONE process (boxes and moments
 // differ by +-3 %, more than most of these choices). Acc<fp64, fp32>, lower /
-// unit. Usage: tune_trsv_split n rounds first:parts:tail_blocks:tail_parts:tail_deferred ...
+// unit. Usage: tune_trsv_split n rounds first:parts:tail_blocks:tail_parts:tail_deferred[:last_blocks:last_parts] ...
 // (first = 0: the library's rule for everything)
 #include <hip/hip_runtime.h>
 
@@ -46,7 +46,7 @@ __global__ void fill(st_type *p, size_t n, unsigned seed, float scale)
 int main(int argc, char **argv)
 {
     if (argc < 4) {
-        std::fprintf(stderr, "usage: tune_trsv_split n rounds first:parts:tail_blocks:tail_parts:tail_deferred ...\n");
+        std::fprintf(stderr, "usage: tune_trsv_split n rounds first:parts:tail_blocks:tail_parts:tail_deferred[:last_blocks:last_parts] ...\n");
         return 2;
     }
     const long n = std::atol(argv[1]);
@@ -57,24 +57,27 @@ int main(int argc, char **argv)
     std::vector<std::string> names;
     std::vector<trsv_wide_split> splits;
     for (int a = 3; a < argc; ++a) {
-        int first, parts, tail_blocks, tail_parts, tail_deferred;
-        if (std::sscanf(argv[a], "%d:%d:%d:%d:%d", &first, &parts, &tail_blocks, &tail_parts,
-                        &tail_deferred) != 5) {
+        int first, parts, tail_blocks, tail_parts, tail_deferred, last_blocks = 0, last_parts = 1;
+        if (std::sscanf(argv[a], "%d:%d:%d:%d:%d:%d:%d", &first, &parts, &tail_blocks, &tail_parts,
+                        &tail_deferred, &last_blocks, &last_parts) < 5) {
             std::fprintf(stderr, "bad config %s\n", argv[a]);
             return 2;
         }
         trsv_wide_split split = trsv_wide_split_for(n, prop.multiProcessorCount);
         if (first > 0) {
             if (first < 98 || parts < 2 || parts > trsv_wide_max_parts || tail_parts < 2 ||
-                tail_parts > trsv_wide_max_parts || tail_deferred < 1 || tail_deferred > 48) {
+                tail_parts > trsv_wide_max_parts || tail_deferred < 1 || tail_deferred > 48 ||
+                last_parts < 1 || last_parts > trsv_wide_max_parts || last_blocks < 0) {
                 std::fprintf(stderr, "config out of range %s\n", argv[a]);
                 return 2;
             }
             if (blocks > first) {
                 tail_blocks = std::min(tail_blocks, blocks - first);
-                split = trsv_wide_split{first, parts, blocks - tail_blocks, tail_parts, tail_deferred};
+                last_blocks = std::min(last_blocks, tail_blocks);
+                split = trsv_wide_split{first, parts, blocks - tail_blocks, tail_parts, tail_deferred,
+                                        blocks - last_blocks, last_parts};
             } else {
-                split = trsv_wide_split{blocks, 1, blocks, 1, 48};
+                split = trsv_wide_split{blocks, 1, blocks, 1, 48, blocks, 1};
             }
         }
         names.push_back(argv[a]);
@@ -132,9 +135,10 @@ int main(int argc, char **argv)
     for (size_t i = 0; i < splits.size(); ++i) {
         auto t = times[i];
         std::sort(t.begin(), t.end());
-        std::printf("  %-18s first %3d parts %2d tail from %3d parts %2d keep %2d | min %8.1f med %8.1f us | %6.1f GB/s (min) | sum|x| %.9e\n",
+        std::printf("  %-24s first %3d parts %2d tail from %3d parts %2d keep %2d last from %3d parts %2d | min %8.1f med %8.1f us | %6.1f GB/s (min) | sum|x| %.9e\n",
                     names[i].c_str(), splits[i].first_block, splits[i].parts, splits[i].tail_block,
-                    splits[i].tail_parts, splits[i].tail_deferred, t.front() * 1e3, t[t.size() / 2] * 1e3,
+                    splits[i].tail_parts, splits[i].tail_deferred, splits[i].last_block, splits[i].last_parts,
+                    t.front() * 1e3, t[t.size() / 2] * 1e3,
                     bytes / (t.front() * 1e-3) / 1e9, checksum[i]);
     }
     return 0;

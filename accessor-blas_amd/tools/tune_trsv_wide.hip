@@ -70,10 +70,30 @@ int main(int argc, char **argv)
     c_range m(sz{{n, n}}, (const st_type *)A, st{{n}});
     range xv(sz{{n, 1}}, x, st{{1}});
     const unsigned blocks = unsigned((n + 127) / 128);
+    // argv[5]: first:parts:tail_blocks:tail_parts:tail_deferred[:last_blocks:last_parts]
+    // as tune_trsv_split takes it (default: the library's rule)
+    trsv_wide_split split = trsv_wide_split_for(n, 256);
+    if (argc > 5) {
+        int first, parts, tail_blocks, tail_parts, tail_deferred, last_blocks = 0, last_parts = 1;
+        if (std::sscanf(argv[5], "%d:%d:%d:%d:%d:%d:%d", &first, &parts, &tail_blocks, &tail_parts,
+                        &tail_deferred, &last_blocks, &last_parts) < 5) {
+            std::fprintf(stderr, "bad split %s\n", argv[5]);
+            return 2;
+        }
+        if (first > 0 && int(blocks) > first) {
+            tail_blocks = std::min(tail_blocks, int(blocks) - first);
+            last_blocks = std::min(last_blocks, tail_blocks);
+            split = trsv_wide_split{first, parts, int(blocks) - tail_blocks, tail_parts, tail_deferred,
+                                    int(blocks) - last_blocks, last_parts};
+        }
+    }
+    std::printf("split: first %d parts %d tail from %d parts %d keep %d last from %d parts %d\n", split.first_block,
+                split.parts, split.tail_block, split.tail_parts, split.tail_deferred, split.last_block,
+                split.last_parts);
     struct entry { std::string name; std::function<void()> run; };
     std::vector<entry> entries = {
         {"rows64", [&]() { CHECK(launch_trsv<ar_type>(false, true, m, xv, helper, session, nullptr, 1)); }},
-        {"rows128", [&]() { CHECK(launch_trsv_wide<ar_type>(false, true, m, xv, helper, session, nullptr, 256)); }},
+        {"rows128", [&]() { CHECK(launch_trsv_wide_split<ar_type>(false, true, m, xv, helper, session, nullptr, split)); }},
     };
     hipEvent_t start, stop;
     CHECK(hipEventCreate(&start));
@@ -106,8 +126,8 @@ int main(int argc, char **argv)
     CHECK(hipMemset(diag, 0, size_t(blocks) * 8 * 20 * 8));
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_wide_diag_buffer), &diag, sizeof(diag)));
     unsigned long long *records;
-    CHECK(hipMalloc(&records, size_t(blocks) * 16 * 8 * 8));
-    CHECK(hipMemset(records, 0, size_t(blocks) * 16 * 8 * 8));
+    CHECK(hipMalloc(&records, size_t(blocks) * trsv_wide_max_parts * 8 * 8));
+    CHECK(hipMemset(records, 0, size_t(blocks) * trsv_wide_max_parts * 8 * 8));
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(trsv_wide_diag_workgroups), &records, sizeof(records)));
     CHECK(hipMemcpy(x, x0, n * sizeof(st_type), hipMemcpyDeviceToDevice));
     entries[1].run();
@@ -142,7 +162,7 @@ int main(int argc, char **argv)
     // where the bytes flow: every workgroup's columns, spread over the time it
     // caught up in bulk and then placed at the moments the front handed them over
     {
-        std::vector<unsigned long long> rec(size_t(blocks) * 128);
+        std::vector<unsigned long long> rec(size_t(blocks) * trsv_wide_max_parts * 8);
         CHECK(hipMemcpy(rec.data(), records, rec.size() * 8, hipMemcpyDeviceToHost));
         auto t_of = [&](unsigned long long v) { return (double)(long long)(v - t0) * 0.01; };
         std::vector<double> pubt(blocks);
@@ -164,8 +184,8 @@ int main(int argc, char **argv)
             }
         };
         for (unsigned b = 0; b < blocks; ++b) {
-            for (int p = 0; p < 16; ++p) {
-                const unsigned long long *r = &rec[(size_t(b) * 16 + p) * 8];
+            for (int p = 0; p < trsv_wide_max_parts; ++p) {
+                const unsigned long long *r = &rec[(size_t(b) * trsv_wide_max_parts + p) * 8];
                 if (r[7] != 1) continue;
                 const double start = t_of(r[0]), sweep0 = t_of(r[1]), end = t_of(r[4]);
                 const long c0 = long(r[5]), c1 = long(r[6]);

@@ -226,8 +226,9 @@ def test_trsv_split_row_blocks_match_oracle_and_unsplit_bits(gpu, ar, st, unit, 
     repeatable, and with the SAME summation structure whatever the helpers'
     timing (a second solve gives the same bits)."""
     torch, accblas = gpu
-    # 157 row blocks: 100..124 in 5 parts (owners keep 48 columns), 125..156 in
-    # 8 parts (owners keep 16), the last block ragged
+    # 157 row blocks: 100..124 in 5 parts (owners keep 48 columns), 125..146 in
+    # 8 parts and 147..156 in 16 parts (owners keep 16; an owner takes the 15
+    # helpers' sums through LDS in three rounds), the last block ragged
     n, lda = 20008, 20016
     rng = np.random.default_rng(78)
     full = rng.uniform(-1.0, 1.0, (n, lda)) / np.sqrt(n)
