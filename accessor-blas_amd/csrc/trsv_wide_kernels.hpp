@@ -559,7 +559,10 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     // The first few blocks are due before a fold (~14 us) could finish: they
     // treat x_{b-1} as one more far column (a reduction and the c mat-vec on
     // their hop, ~0.6 us more) and start the chain ~15 us earlier.
-    constexpr index_type unfolded_blocks = 6;
+#ifndef ACCBLAS_TRSV_WIDE_UNFOLDED
+#define ACCBLAS_TRSV_WIDE_UNFOLDED 6
+#endif
+    constexpr index_type unfolded_blocks = ACCBLAS_TRSV_WIDE_UNFOLDED;
     const bool folded = block >= unfolded_blocks;
     if (folded && !defer_fold && !helper_part) {
         fold_panel();
