@@ -467,7 +467,7 @@ using gemv_skew_config = gemv_config<8, 2, 2, 2, true>;
  *  against nine other shapes in profiles/r01_gemv_row_align_ab.txt. */
 using gemv_row_align_config = gemv_config<8, 4, 4, 1, true>;
 
-/** Short rows (at most `gemv_short_row_bytes` of storage per row: the first
+/** Short rows (at most `gemv_short_row_bytes<St>` of storage per row: the first
  *  quarter of the reference's sweep, cuda/gemv_benchmark.cu:211-214, and tall
  *  matrices): the production shape covers 8 KiB of a row per step and would run
  *  such rows through its ragged end only, with 8 rows per workgroup a small
@@ -484,11 +484,30 @@ using gemv_row_align_config = gemv_config<8, 4, 4, 1, true>;
  *  Acc<fp64,fp32> n = 1300 6.80 -> 6.24 | 6.28, 1900 8.04 -> 6.24 | 6.68,
  *  2200 9.84 -> 6.56 | 8.32, 3000 11.4 -> 9.5 | 13.7, 4500 21.2 -> 17.2 | 23.7;
  *  fp64 2200 13.4 -> 9.5 | 12.8; 24000 x 2000 Acc<fp64,fp32> 40.1 -> 33.5 |
- *  52.0. Beyond 24 KiB per row the production shape is as fast or faster. */
+ *  52.0.
+ *  How long "short" is depends on the storage type. The production shape has 8
+ *  rows per workgroup: a CU gets ceil(rows / 8 / 256) of them, and just past a
+ *  multiple of 2048 rows that is one more for a few CUs - n = 4100 takes 25 %
+ *  longer than n = 4000, n = 6200 32 % longer than 6000 - while the matrix
+ *  still streams faster than HBM (Infinity Cache) and the balance between the
+ *  CUs is what counts. The short shapes have 1 or 4 rows per workgroup. Measured
+ *  (profiles/r03_tune_gemv_mid.txt, lda = 24500, us, production shape -> best
+ *  short shape | rocBLAS): fp64 n = 3100 19.4 -> 16.7 | 17.9, 3500 21.2 -> 19.3
+ *  | 19.7, 4000 24.2 -> 24.2 | 23.7, 4100 30.2 -> 25.8 | 27.9, 4500 33.8 ->
+ *  29.8 | 32.0, 5000 37.8 -> 34.2 | 38.0, 5200 40.5 -> 40.5, 5500 42.9 -> 43.6;
+ *  Acc<fp64,fp32> 6200 34.7 -> 30.8 | 38.0, 6500 35.9 -> 32.3, 7000 38.1 ->
+ *  34.9, 8000 43.3 -> 45.4. So: 40 KiB per row with 8-byte storage, 28 KiB with
+ *  4-byte storage, 24 KiB with 2-byte storage (not measured beyond). Tall
+ *  matrices of such rows lose 2 % (24000 x 4000 fp64: 120.9 -> 123.2). */
 using gemv_short_config = gemv_config<2, 2, 1, 2, true>;
 using gemv_short_tall_config = gemv_config<4, 2, 2, 2, true>;
-constexpr index_type gemv_short_row_bytes = 24576;
-constexpr index_type gemv_short_max_rows = 4608;  // above: the two-row shape
+template <typename StorageType>
+constexpr index_type gemv_short_row_bytes =
+    sizeof(StorageType) == 8
+        ? index_type{40} << 10
+        : (sizeof(StorageType) == 4 ? index_type{28} << 10
+                                    : index_type{24} << 10);
+constexpr index_type gemv_short_max_rows = 4352;  // above: the two-row shape
 static_assert(gemv_short_config::wpr == gemv_short_tall_config::wpr &&
                   gemv_short_config::unroll == gemv_short_tall_config::unroll,
               "the two short-row shapes must sum a row in the same order");
@@ -596,7 +615,7 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
                            stream>>>(alpha, mtx, x, beta, res);
                 } else if (std::is_same<Config, gemv_default_config>::value &&
                            cols * static_cast<index_type>(sizeof(st_type)) <=
-                               gemv_short_row_bytes) {
+                               gemv_short_row_bytes<st_type>) {
                     // short rows (the choice between the two shapes does not
                     // change the bits of a row, see gemv_short_config)
                     if (rows <= gemv_short_max_rows) {

@@ -1286,6 +1286,11 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
         split.last_block < split.tail_block) {
         return hipErrorInvalidValue;
     }
+    if (split.parts == 1 && (split.tail_parts != 1 || split.last_parts != 1)) {
+        // (no splitting means none at all: the grid would hold workgroups
+        // that no row block is waiting for)
+        return hipErrorInvalidValue;
+    }
     if (split.parts > 1) {
         // a split block adds its helpers' sums where it folds its panel, which
         // it only does late (`defer_fold`) when it has at least

@@ -131,6 +131,7 @@ void sweep(const char *title, long lda, int reps, rocblas_handle blas)
         ADD(4, 4, 2, 1)
         ADD(8, 2, 1, 2)
         ADD(8, 4, 2, 2)
+        ADD(8, 4, 1, 2)
         ADD(8, 2, 2, 2)
     } else {
     ADD(8, 4, 4, 1)
@@ -185,8 +186,9 @@ void sweep(const char *title, long lda, int reps, rocblas_handle blas)
     }});
 
     const std::vector<long> sizes =
-        fine_pass ? std::vector<long>{2000, 3000, 3500, 4000, 4100, 4500, 5000, 5500, 6000,
-                                      7000, 8000, 8200, 10000, -1000, -2000, -3000, -4000}
+        fine_pass ? std::vector<long>{2000, 3000, 3100, 3300, 3500, 4000, 4100, 4500, 5000, 5200,
+                                      5500, 6000, 6200, 6500, 7000, 8000, 8200, 10000, -1000,
+                                      -2000, -3000, -4000}
                   : std::vector<long>{100,  500,  900,  1100, 1300, 1600, 1900, 2200,
                                       2500, 3000, 3500, 4000, 4100, 4500, 5000, 6000};
     // (a negative size -c stands for the tall case 24000 rows x c columns)

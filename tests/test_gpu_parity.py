@@ -72,6 +72,9 @@ GEMV_SHAPES = [
     (1900, 1900, 24500, 0),
     (2200, 2200, 24500, 0),
     (5000, 1500, 1504, 0),  # short rows, many of them: the two-row shape
+    # rows that count as short for 8-byte (up to 40 KiB) / 4-byte (28 KiB) storage only
+    (600, 4100, 4104, 0),
+    (500, 6500, 6504, 0),
 ]
 
 
@@ -116,20 +119,21 @@ def test_plain_gemv_equals_accessor_bitwise(gpu, vt, rows, cols, lda, offset):
     assert not torch.equal(r_plain, to_dev(torch, res0)) or cols == 0
 
 
+@pytest.mark.parametrize("cols", [2000, 4500])  # 4500: short for fp64 and fp32 storage only by the longer limits
 @pytest.mark.parametrize("ar,st", [(F64, F32), (F64, F64), (F32, F16)])
-def test_gemv_row_blocks_of_short_rows_keep_their_bits(gpu, ar, st):
+def test_gemv_row_blocks_of_short_rows_keep_their_bits(gpu, ar, st, cols):
     """Short rows pick one of two workgroup shapes by the NUMBER of rows; a
     row's summation order is the same in both, so a row block (what one GPU of
     a sharded GEMV computes) has the bits of the same rows inside the taller
     product, on either side of the row-count rule."""
     torch, accblas = gpu
-    rows, cols, lda = 6000, 2000, 2048
+    rows, lda = 6000, cols + 8
     A = to_dev(torch, make_inputs(41, rows * lda, st))
     x = to_dev(torch, make_inputs(42, cols, st))
     res0 = make_inputs(43, rows, st)
     full = to_dev(torch, res0)
     accblas.acc_gemv(ar, st, rows, cols, 1.0, A, lda, x, 1, 1.0, full, 1)
-    for lo, hi in [(0, 1000), (1000, 1001), (1024, 5000), (5000, 6000)]:
+    for lo, hi in [(0, 1000), (1000, 1001), (1024, 5500), (5000, 6000)]:
         part = to_dev(torch, res0)
         accblas.acc_gemv(ar, st, hi - lo, cols, 1.0, A[lo * lda:], lda, x, 1, 1.0,
                          part[lo:], 1)
