@@ -534,8 +534,10 @@ def main():
     accblas.acc_gemv(ar, st, rows, cols, 1.0, A_st, lda, x_st, 1, 1.0, res_st, 1, stream)
     torch.cuda.synchronize()
     first_result = res_st.clone()
+    # (the master's 8.6 GB stay in torch's allocator: device memory handed back to
+    # the driver is cleared in the background, and launches that run meanwhile
+    # stream 2-5 % slower for seconds - profiles/r03_gemv_data_dependence.txt)
     del A64
-    torch.cuda.empty_cache()
 
     def barrier():
         torch.cuda.synchronize()
@@ -611,8 +613,7 @@ def main():
     sample_rows = min(rows, 16384)
     want_cpu = world == 1 and not args.no_cpu_baseline
     A_sample = A_st[: sample_rows * lda].cpu().numpy() if want_cpu else None
-    del A_st
-    torch.cuda.empty_cache()
+    del A_st  # (kept in the allocator, see above: the other configs are timed next)
     extras = None
     if not args.no_other_configs and n == 32768:
         extras = other_configs(accblas, torch, dev, stream, dist, world, rank)
