@@ -131,9 +131,11 @@ struct mma_slot<float> {
 template <typename T>
 __device__ __forceinline__ T quad_column_sum(T value)
 {
-    value += __shfl_xor(value, 16, wave_size);
-    value += __shfl_xor(value, 32, wave_size);
-    return value;
+    // (value + the lane 16 away, then + the lane 32 away, as two
+    // `__shfl_xor` steps would give - without their trips through LDS: this
+    // sum ends both c and W x on the chain's hop)
+    value = lane_bit_pair_sum<4>(value);
+    return lane_bit_pair_sum<5>(value);
 }
 
 

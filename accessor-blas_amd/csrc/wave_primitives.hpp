@@ -72,6 +72,63 @@ __device__ __forceinline__ T dpp_move(T value)
 }
 
 
+/** Both halves of a lane-bit-4 / lane-bit-5 exchange in one vector-ALU
+ *  instruction per 32-bit word (gfx950: `v_permlane16_swap_b32`,
+ *  `v_permlane32_swap_b32`), where `__shfl_xor(v, 16 | 32)` is a
+ *  `ds_bpermute_b32` through the LDS crossbar. With the same register as both
+ *  operands the swap leaves `low` = the value of the lane whose bit is CLEAR
+ *  and `high` = the value of the lane whose bit is SET, in both lanes of every
+ *  pair. */
+template <typename T>
+struct lane_pair {
+    T low;
+    T high;
+};
+
+template <int Bit, typename T>
+__device__ __forceinline__ lane_pair<T> lane_bit_pair(T value)
+{
+    static_assert(Bit == 4 || Bit == 5, "lane bit 4 (rows of 16) or 5 (halves)");
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4/8-byte values only");
+    unsigned int words[sizeof(T) / 4];
+    unsigned int low[sizeof(T) / 4];
+    unsigned int high[sizeof(T) / 4];
+    __builtin_memcpy(words, &value, sizeof(T));
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) {
+        const auto both =
+            Bit == 4 ? __builtin_amdgcn_permlane16_swap(words[i], words[i],
+                                                        false, false)
+                     : __builtin_amdgcn_permlane32_swap(words[i], words[i],
+                                                        false, false);
+        low[i] = both[0];
+        high[i] = both[1];
+    }
+    lane_pair<T> out;
+    __builtin_memcpy(&out.low, low, sizeof(T));
+    __builtin_memcpy(&out.high, high, sizeof(T));
+    return out;
+}
+
+/** `value` of the lane whose lane bit `Bit` (4 or 5) differs:
+ *  `__shfl_xor(value, 1 << Bit)` without the LDS crossbar. */
+template <int Bit, typename T>
+__device__ __forceinline__ T lane_bit_partner(T value, int lane)
+{
+    const lane_pair<T> both = lane_bit_pair<Bit>(value);
+    return ((lane >> Bit) & 1) ? both.low : both.high;
+}
+
+/** value + `__shfl_xor(value, 1 << Bit)`, same bits in both lanes of a pair
+ *  (the sum of the same two numbers in either order). */
+template <int Bit, typename T>
+__device__ __forceinline__ T lane_bit_pair_sum(T value)
+{
+    const lane_pair<T> both = lane_bit_pair<Bit>(value);
+    return both.low + both.high;
+}
+
+
 /**
  * Sums Count values per lane over groups of `Width` consecutive lanes
  * (Count a power of two <= 16, Width = 16, 32 or 64) in
@@ -79,7 +136,8 @@ __device__ __forceinline__ T dpp_move(T value)
  * (a transposing butterfly): Count - 1 + log2(Width / Count) lane moves per
  * lane instead of Count * log2(Width). Exchanges over lane bits 0..3 are DPP
  * moves (bits 2 and 3 as rotations inside the 16-lane row, which pair every
- * lane with one whose bit differs), bits 4 and 5 `__shfl_xor`. Every lane of a
+ * lane with one whose bit differs), bits 4 and 5 `lane_bit_partner` (one
+ * `v_permlane16/32_swap` per word). Every lane of a
  * group ends with a total of value index `lane & (Count - 1)`; fixed order,
  * so the result is reproducible. ONLY lanes [0, Count) of each group hold the
  * canonical total: the rotations used for lane bits 2 and 3 are one-way moves,
@@ -102,7 +160,7 @@ __device__ __forceinline__ T transpose_reduce_sum(const T (&values)[Count],
         cur[i] = values[i];
     }
     // from[bit](v) = v of the lane paired with this one across lane bit `bit`
-    const auto from = [](auto bit_tag, T v) -> T {
+    const auto from = [lane](auto bit_tag, T v) -> T {
         constexpr int bit = decltype(bit_tag)::value;
         if (bit == 0) {
             return dpp_move<dpp_quad_swap_1>(v);
@@ -113,7 +171,7 @@ __device__ __forceinline__ T transpose_reduce_sum(const T (&values)[Count],
         } else if (bit == 3) {
             return dpp_move<dpp_row_rotate_8>(v);
         } else {
-            return __shfl_xor(v, 1 << bit, wave_size);
+            return lane_bit_partner<(bit < 4 ? 4 : bit)>(v, lane);
         }
     };
     constexpr int halving_steps = Count == 1 ? 0 : (Count == 2 ? 1 : (Count == 4 ? 2 : (Count == 8 ? 3 : 4)));

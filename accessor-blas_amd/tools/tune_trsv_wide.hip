@@ -28,7 +28,10 @@
 
 using namespace accblas::dev;
 using ar_type = double;
-using st_type = float;
+#ifndef TUNE_ST_TYPE
+#define TUNE_ST_TYPE float
+#endif
+using st_type = TUNE_ST_TYPE;
 using accessor = gko::acc::reduced_row_major<2, ar_type, st_type>;
 using range = gko::acc::range<accessor>;
 using c_range = gko::acc::range<accessor::const_accessor>;
@@ -40,7 +43,7 @@ __global__ void fill(st_type *p, size_t n, unsigned seed, float scale)
     for (; i < n; i += stride) {
         unsigned h = unsigned(i) * 2654435761u + seed;
         h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-        p[i] = ((h & 0xffffff) / float(0x800000) - 1.0f) * scale;
+        p[i] = static_cast<st_type>(((h & 0xffffff) / float(0x800000) - 1.0f) * scale);
     }
 }
 
