@@ -1089,12 +1089,14 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        const ar_type total = group_all_reduce<LPR>(
-            acc[k], [](ar_type a, ar_type b) { return a + b; });
-        if (worker && col_group == 0) {
-            const int r = wave * RW + k * Vec + row_in_inst;
+    {
+        // NI sums per lane over the LPR lanes of a row group: a transposing
+        // butterfly on DPP moves (lane k of a group ends with the total of sum
+        // k) instead of NI x log2(LPR) shuffles through the LDS crossbar,
+        // which sat on every hop of the chain
+        const ar_type total = transpose_reduce_sum<NI, LPR>(acc, lane);
+        if (worker && col_group < NI) {
+            const int r = wave * RW + col_group * Vec + row_in_inst;
             correction[r] = (base + r < n) ? total : ar_type{};
         }
     }

@@ -54,6 +54,7 @@ constexpr int dpp_quad_swap_1 = 0xB1;   // quad_perm:[1,0,3,2]: lane ^ 1
 constexpr int dpp_quad_swap_2 = 0x4E;   // quad_perm:[2,3,0,1]: lane ^ 2
 constexpr int dpp_row_rotate_4 = 0x124;  // row_ror:4 inside each 16-lane row
 constexpr int dpp_row_rotate_8 = 0x128;  // row_ror:8
+constexpr int dpp_row_rotate_12 = 0x12C;  // row_ror:12: lane l reads lane l + 4 (mod 16)
 
 /** `value` of the lane that DPP control `Ctrl` names (4- and 8-byte types). */
 template <int Ctrl, typename T>
@@ -131,7 +132,7 @@ __device__ __forceinline__ T lane_bit_pair_sum(T value)
 
 /**
  * Sums Count values per lane over groups of `Width` consecutive lanes
- * (Count a power of two <= 16, Width = 16, 32 or 64) in
+ * (Count a power of two <= 16, Width = 8, 16, 32 or 64) in
  * log2(Width) exchange steps that HALVE the number of values a lane carries
  * (a transposing butterfly): Count - 1 + log2(Width / Count) lane moves per
  * lane instead of Count * log2(Width). Exchanges over lane bits 0..3 are DPP
@@ -144,7 +145,9 @@ __device__ __forceinline__ T lane_bit_pair_sum(T value)
  * not swaps, so when such a step is a plain all-reduce (Count <= 4 or 8) the
  * lanes of different quads add the same partial sums in different association
  * orders and may differ from each other in the last bit. Callers read lanes
- * [0, Count) (`col_group < NI` in the TRSV kernels).
+ * [0, Count) (`col_group < NI` in the TRSV kernels). Width = 8: the rotation
+ * over lane bit 2 reaches into the neighbouring group for lanes 4..7 of a
+ * group, so there lanes [0, Count) are the only ones with a total at all.
  */
 template <int Count, int Width, typename T>
 __device__ __forceinline__ T transpose_reduce_sum(const T (&values)[Count],
@@ -152,8 +155,9 @@ __device__ __forceinline__ T transpose_reduce_sum(const T (&values)[Count],
 {
     static_assert(Count >= 1 && (Count & (Count - 1)) == 0 && Count <= 16,
                   "Count must be a power of two <= 16");
-    static_assert((Width == 16 || Width == 32 || Width == 64) && Count <= Width,
-                  "Width must be 16, 32 or 64 lanes");
+    static_assert((Width == 8 || Width == 16 || Width == 32 || Width == 64) &&
+                      Count <= Width && (Width > 8 || Count <= 4),
+                  "Width must be 8 (Count <= 4), 16, 32 or 64 lanes");
     T cur[Count];
 #pragma unroll
     for (int i = 0; i < Count; ++i) {
@@ -167,7 +171,11 @@ __device__ __forceinline__ T transpose_reduce_sum(const T (&values)[Count],
         } else if (bit == 1) {
             return dpp_move<dpp_quad_swap_2>(v);
         } else if (bit == 2) {
-            return dpp_move<dpp_row_rotate_4>(v);
+            // (row_ror:4 hands lane l the value of lane l - 4: any partner
+            // inside a 16-lane group will do, in a group of 8 lanes 0..3 need
+            // lanes 4..7)
+            return Width == 8 ? dpp_move<dpp_row_rotate_12>(v)
+                              : dpp_move<dpp_row_rotate_4>(v);
         } else if (bit == 3) {
             return dpp_move<dpp_row_rotate_8>(v);
         } else {
@@ -175,7 +183,8 @@ __device__ __forceinline__ T transpose_reduce_sum(const T (&values)[Count],
         }
     };
     constexpr int halving_steps = Count == 1 ? 0 : (Count == 2 ? 1 : (Count == 4 ? 2 : (Count == 8 ? 3 : 4)));
-    constexpr int all_steps = Width == 16 ? 4 : (Width == 32 ? 5 : 6);
+    constexpr int all_steps =
+        Width == 8 ? 3 : (Width == 16 ? 4 : (Width == 32 ? 5 : 6));
     // halving steps: a lane keeps the values whose index bit equals its own
     // lane bit and receives the partner's copies of those
     const auto halve = [&](auto bit_tag, int live) {

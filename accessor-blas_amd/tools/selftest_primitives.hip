@@ -51,6 +51,8 @@ struct results {
     double transpose_16_64[64];
     double transpose_1_64[64];
     float transpose_2_16[64];
+    double transpose_1_8[64];
+    double transpose_4_32[64];
 };
 
 __global__ __launch_bounds__(256) void reductions(results *out)
@@ -106,6 +108,8 @@ __global__ __launch_bounds__(64) void transposes(results *out)
     out->transpose_16_64[lane] = transpose_case<16, 64, double>(lane);
     out->transpose_1_64[lane] = transpose_case<1, 64, double>(lane);
     out->transpose_2_16[lane] = transpose_case<2, 16, float>(lane);
+    out->transpose_1_8[lane] = transpose_case<1, 8, double>(lane);
+    out->transpose_4_32[lane] = transpose_case<4, 32, double>(lane);
 }
 
 __global__ __launch_bounds__(256) void atomics(results *out)
@@ -177,6 +181,10 @@ int main()
         expect(host.transpose_16_64[l] == transpose_want(16, 64, l), "transpose_reduce_sum<16, 64>");
         expect(host.transpose_1_64[l] == transpose_want(1, 64, l), "transpose_reduce_sum<1, 64>");
         expect(host.transpose_2_16[l] == float(transpose_want(2, 16, l)), "transpose_reduce_sum<2, 16>");
+        expect(host.transpose_4_32[l] == transpose_want(4, 32, l), "transpose_reduce_sum<4, 32>");
+        if (l % 8 == 0) {  // Width 8: lanes [0, Count) of a group only
+            expect(host.transpose_1_8[l] == transpose_want(1, 8, l), "transpose_reduce_sum<1, 8>");
+        }
     }
     if (failures == 0) {
         std::printf("primitives ok\n");
