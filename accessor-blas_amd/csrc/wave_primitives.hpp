@@ -217,15 +217,22 @@ __device__ __forceinline__ T transpose_reduce_sum(const T (&values)[Count],
 
 /**
  * Sum over the 64 lanes of a wave; the total is valid in lane 0 (other lanes
- * hold partial garbage). Uses shfl_down: offsets 32, 16, 8, 4, 2, 1.
+ * hold partial garbage). The tree of `__shfl_down` with offsets 32, 16, 8, 4,
+ * 2, 1 - lane 0 ends with exactly those bits - on vector-ALU lane moves
+ * (`v_permlane32/16_swap`, DPP row rotations and quad permutations) instead of
+ * six trips through the LDS crossbar per value: a GEMV workgroup reduces up to
+ * four rows this way at the end of its short life.
  */
 template <typename T>
 __device__ __forceinline__ T wave_reduce_sum(T value)
 {
-#pragma unroll
-    for (int offset = wave_size / 2; offset > 0; offset >>= 1) {
-        value += __shfl_down(value, offset, wave_size);
-    }
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4/8-byte values only");
+    value = lane_bit_pair_sum<5>(value);               // l + (l + 32)
+    value = lane_bit_pair_sum<4>(value);               // + (l + 16)
+    value += dpp_move<dpp_row_rotate_8>(value);        // + (l + 8) for l < 8
+    value += dpp_move<dpp_row_rotate_12>(value);       // + (l + 4) for l < 4
+    value += dpp_move<dpp_quad_swap_2>(value);         // + (l + 2) for l < 2
+    value += dpp_move<dpp_quad_swap_1>(value);         // lane 0 + lane 1
     return value;
 }
 

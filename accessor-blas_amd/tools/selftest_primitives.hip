@@ -51,6 +51,9 @@ struct results {
     double transpose_16_64[64];
     double transpose_1_64[64];
     float transpose_2_16[64];
+    // wave_reduce_sum against the __shfl_down tree it replaces, rounding included
+    double tree_new_f64[4], tree_old_f64[4];
+    float tree_new_f32[4], tree_old_f32[4];
     double transpose_1_8[64];
     double transpose_4_32[64];
 };
@@ -67,6 +70,25 @@ __global__ __launch_bounds__(256) void reductions(results *out)
         group_all_reduce<64>(value, [](double a, double b) { return a + b; });
     out->group16[threadIdx.x] =
         group_all_reduce<16>(value, [](double a, double b) { return a + b; });
+    {
+        // values whose sum depends on the order of the additions
+        const double rough = 1.0 / (3.0 + threadIdx.x) + 1e-9 * threadIdx.x * threadIdx.x;
+        const float rough_f = static_cast<float>(rough) * 1.000123f;
+        double old_d = rough;
+        float old_f = rough_f;
+        for (int offset = 32; offset > 0; offset >>= 1) {
+            old_d += __shfl_down(old_d, offset, 64);
+            old_f += __shfl_down(old_f, offset, 64);
+        }
+        const double new_d = wave_reduce_sum(rough);
+        const float new_f = wave_reduce_sum(rough_f);
+        if (lane_id() == 0) {
+            out->tree_new_f64[wave_id()] = new_d;
+            out->tree_old_f64[wave_id()] = old_d;
+            out->tree_new_f32[wave_id()] = new_f;
+            out->tree_old_f32[wave_id()] = old_f;
+        }
+    }
     const double total = block_reduce_sum<4>(value, scratch);
     if (threadIdx.x == 0) {
         out->block_sum = total;
@@ -150,6 +172,10 @@ int main()
     for (int w = 0; w < 4; ++w) {
         const double want = 64.0 * (64 * w) + 64.0 * 65 / 2;  // sum of 64w+1 .. 64w+64
         expect(host.wave_sum[w] == want, "wave_reduce_sum");
+        expect(host.tree_new_f64[w] == host.tree_old_f64[w] && host.tree_new_f64[w] > 0.0,
+               "wave_reduce_sum: the bits of the __shfl_down tree (fp64)");
+        expect(host.tree_new_f32[w] == host.tree_old_f32[w] && host.tree_new_f32[w] > 0.0f,
+               "wave_reduce_sum: the bits of the __shfl_down tree (fp32)");
         for (int l = 0; l < 64; ++l) {
             expect(host.wave_all[64 * w + l] == want, "group_all_reduce<64>");
         }
