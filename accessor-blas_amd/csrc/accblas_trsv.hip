@@ -15,6 +15,7 @@ namespace {
 std::atomic<int> trsv_wide_option{1};
 std::atomic<int> trsv_relay_option{1};
 std::atomic<int> trsv_split_from_option{0};
+std::atomic<int> trsv_prefetch_option{1};
 std::atomic<int> gemv_skew_option_store{1};
 }
 
@@ -25,6 +26,8 @@ int accblas::trsv_split_from_option_value()
 {
     return trsv_split_from_option.load();
 }
+
+int accblas::trsv_prefetch_option_value() { return trsv_prefetch_option.load(); }
 
 int accblas::trsv_num_cus()
 {
@@ -65,6 +68,8 @@ extern "C" int accblas_set_option(const char *name, int value)
         target = &trsv_wide_option;
     } else if (key == "trsv_relay") {
         target = &trsv_relay_option;
+    } else if (key == "trsv_prefetch") {
+        target = &trsv_prefetch_option;
     } else if (key == "gemv_skew") {
         target = &gemv_skew_option_store;
     } else {

@@ -63,19 +63,31 @@ int trsv_wide_option_value();
 /** Option "trsv_wide_split_from": 0 = the first split row block by the rule
  *  (`trsv_wide_split_for`, default), k > 0 = block k (tests, experiments). */
 int trsv_split_from_option_value();
+/** Option "trsv_prefetch": 0 = no prefetching workgroups, 1 = by the measured
+ *  rule (default, `trsv_wide_prefetchers_for`), 2 = whenever CUs are idle. */
+int trsv_prefetch_option_value();
 /** Option "trsv_relay": 0 never, 1 by the measured rule (default), 2 always. */
 int trsv_relay_option_value();
 
-/** From these sizes on the 128-row kernel is the faster one
- *  (profiles/r02_trsv_ab_final.txt): 2- and 4-byte storage 4-7 % faster at
- *  n = 4096, 17-20 % at 8192, 27-50 % at 24000-65536; 8-byte storage (two
- *  half-width steps in flight are all the registers allow) 3-4 % at 16384,
- *  24000 and 65536, equal at 32768 (profiles/r02_trsv_f64_storage_ab.txt). */
+/** Where the 128-row kernel is the faster one. 2- and 4-byte storage: from
+ *  n = 4096 on (profiles/r02_trsv_ab_final.txt: 4-7 % faster at 4096, 17-20 % at
+ *  8192, 27-50 % at 24000-65536). 8-byte storage (two half-width steps in
+ *  flight are all the registers allow), re-measured at the end of round 3 with
+ *  the lane-move reductions in the 64-row kernel and the prefetching workgroups
+ *  in the 128-row one (profiles/r03_trsv_prefetch.txt, us, 64-row | 128-row |
+ *  128-row with prefetchers): 4096 98 | 104 | 89, 8192 213 | 221 | 164, 16384
+ *  453 | 440 | 389, 18432 437 | 493 | 469 (the 64-row kernel's relay sets in
+ *  at 17000), 24000 645 | 677 | 685, 32768 844 | 973 | 979, 40000 1377 | 1232,
+ *  65536 2746 | 2637: the 128-row kernel from 4096 up to the relay's threshold
+ *  and again where there are more row blocks than CUs. */
 #ifndef ACCBLAS_TRSV_WIDE_MIN_N
 #define ACCBLAS_TRSV_WIDE_MIN_N 4096
 #endif
-#ifndef ACCBLAS_TRSV_WIDE_MIN_N_8BYTE
-#define ACCBLAS_TRSV_WIDE_MIN_N_8BYTE 16384
+#ifndef ACCBLAS_TRSV_WIDE_8BYTE_GAP_FROM
+#define ACCBLAS_TRSV_WIDE_8BYTE_GAP_FROM 17000
+#endif
+#ifndef ACCBLAS_TRSV_WIDE_8BYTE_GAP_TO
+#define ACCBLAS_TRSV_WIDE_8BYTE_GAP_TO 32768
 #endif
 
 
@@ -117,15 +129,17 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
     const int wide = trsv_wide_option_value();
     const bool use_wide =
         wide != 0 && dev::trsv_wide_applicable(upper, mtx) &&
-        (wide == 2 || n >= (sizeof(st_type) < 8
-                                ? ACCBLAS_TRSV_WIDE_MIN_N
-                                : ACCBLAS_TRSV_WIDE_MIN_N_8BYTE));
+        (wide == 2 ||
+         (n >= ACCBLAS_TRSV_WIDE_MIN_N &&
+          (sizeof(st_type) < 8 || n < ACCBLAS_TRSV_WIDE_8BYTE_GAP_FROM ||
+           n > ACCBLAS_TRSV_WIDE_8BYTE_GAP_TO)));
     if (use_wide) {
         return check_hip(
             dev::launch_trsv_wide<ar_type>(upper, unit_diag, mtx, x, helper,
                                            session, as_stream(stream),
                                            trsv_num_cus(),
-                                           trsv_split_from_option_value()),
+                                           trsv_split_from_option_value(),
+                                           trsv_prefetch_option_value()),
             "trsv (128-row) launch");
     }
     return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x, helper,

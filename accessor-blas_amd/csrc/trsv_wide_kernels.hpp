@@ -64,6 +64,11 @@ struct trsv_wide_split {
     int tail_deferred;  // block columns the owner of a tail block keeps
     int last_block;  // blocks from here on (>= tail_block): `last_parts` each,
     int last_parts;  // their owners keep `tail_deferred` columns as well
+    // Workgroups beyond the ones that solve (the last tickets): they run on
+    // CUs the solve leaves idle and pull the tiles of the next block columns
+    // into the Infinity Cache ahead of the chain's front (see
+    // `detail::prefetch_ahead`)
+    int prefetchers;
 };
 constexpr int trsv_wide_max_parts = trsv_partial_slots + 1;
 // helpers' sums an owner takes through LDS at a time
@@ -106,6 +111,94 @@ __device__ unsigned long long *trsv_wide_diag_workgroups;
 
 namespace kernel {
 namespace detail {
+
+
+/** Block columns a prefetching workgroup keeps ahead of the chain's front. */
+constexpr int trsv_wide_prefetch_ahead = 5;
+/** What a prefetching workgroup finds in place of a row block. */
+constexpr std::int32_t trsv_wide_prefetch_block = 0x3ffffffe;
+
+/**
+ * The life of a prefetching workgroup (`trsv_wide_split::prefetchers`): it
+ * follows `trsv_state::front` and touches every cache line of the tiles
+ * (row block b, block column c) for c up to `trsv_wide_prefetch_ahead` columns
+ * beyond the front and b = c + 1 + index, c + 1 + index + count, ... - one
+ * 4-byte load per 128-byte line and thread, the values are thrown away. Why:
+ * a follower's turn-around per block column is the latency of its own tile
+ * (the compiler's loop over the register ring waits for the tile it has just
+ * issued, see profiles/r03_trsv_hop_paths.txt), every block is a follower
+ * until its turn, and a tile that waits in the Infinity Cache arrives sooner
+ * than one that comes from HBM. Measured as a kernel of its own beside the
+ * solve (tools/tune_trsv_prefetch.hip, profiles/r03_trsv_prefetch.txt, 4-byte
+ * storage): n = 6144 -6 %, 8192 -5 %, 12288 -6 %, 16384 -4.5 %, 18432 -2.5 %,
+ * 20480 +1.5 %, 24000 +4.7 % (there the second copy of 12 MB per hop is more
+ * than the fabric has to spare); as workgroups of the solve itself (library
+ * builds alternated in one process): 4096 -3.9 %, 6144 -6.2 %, 12288 -5 %,
+ * 16384 -2.5 %; 8-byte storage 4096 -15 %, 8192 -26 %, 16384 -12 % (its
+ * tiles are twice as large); 2-byte storage +5 % (not used there). Returns when the front is within three block
+ * columns of the end, when another workgroup has given up, or after
+ * `trsv_spin_limit` looks at a front that does not move.
+ */
+template <bool Upper, int R, typename StType>
+__device__ __forceinline__ void prefetch_ahead(const StType *a_data,
+                                               index_type lda, index_type n,
+                                               const trsv_state *state,
+                                               std::uint32_t *helper,
+                                               int index, int count)
+{
+    constexpr int line_elements = 128 / static_cast<int>(sizeof(StType));
+    constexpr int lines_per_row = R / line_elements;  // of one tile row
+    constexpr int lines = R * lines_per_row;          // of one tile
+    const int blocks = static_cast<int>(ceildiv(n, index_type{R}));
+    int done = 2;  // block columns below this are taken care of
+    unsigned int spins = 0;
+    std::uint32_t bits = 0;
+    while (true) {
+        const int front = static_cast<int>(
+            __hip_atomic_load(&state->front, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT));
+        if (front + 3 >= blocks) {
+            break;
+        }
+        const int upto = front + 1 + trsv_wide_prefetch_ahead < blocks - 1
+                             ? front + 1 + trsv_wide_prefetch_ahead
+                             : blocks - 1;
+        done = done < front + 1 ? front + 1 : done;  // (what the front has passed)
+        if (done >= upto) {
+            if (spin_expired(spins, helper)) {
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        for (int c = done; c < upto; ++c) {
+            for (int b = c + 1 + index; b < blocks; b += count) {
+                for (int line = static_cast<int>(threadIdx.x); line < lines;
+                     line += static_cast<int>(blockDim.x)) {
+                    const index_type row =
+                        index_type{b} * R + line / lines_per_row;
+                    const index_type col = index_type{c} * R +
+                                           (line % lines_per_row) * line_elements;
+                    if (row < n) {
+                        const index_type mem_row = Upper ? n - 1 - row : row;
+                        const index_type mem_col =
+                            Upper ? n - 1 - (col + line_elements - 1) : col;
+                        StType value = a_data[mem_row * lda +
+                                              (mem_col > 0 ? mem_col : 0)];
+                        std::uint32_t word = 0;
+                        __builtin_memcpy(&word, &value,
+                                         sizeof(StType) < 4 ? sizeof(StType) : 4);
+                        bits ^= word;
+                    }
+                }
+            }
+        }
+        done = upto;
+    }
+    if (bits == 0x5a17c0deu && spins == 0x7fffffffu) {
+        helper[1] = bits;  // never: keeps the loads alive
+    }
+}
 
 
 /** Where element `within` (0..15) of a 16-wide row of an MFMA result tile
@@ -290,7 +383,15 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         // owner last, so everything a workgroup waits for has a lower ticket
         std::int32_t ticket_block = static_cast<std::int32_t>(ticket);
         std::int32_t ticket_part = 0;
-        if (split.parts > 1 && ticket_block >= split.first_block) {
+        const unsigned int solvers =
+            gridDim.x - static_cast<unsigned int>(split.prefetchers);
+        if (ticket < gridDim.x && ticket >= solvers) {
+            // the last tickets do not solve (`trsv_wide_split::prefetchers`)
+            ticket_block = detail::trsv_wide_prefetch_block;
+            ticket_part = static_cast<std::int32_t>(ticket - solvers);
+        }
+        if (split.parts > 1 && ticket_block >= split.first_block &&
+            ticket_block != detail::trsv_wide_prefetch_block) {
             const std::int32_t beyond = ticket_block - split.first_block;
             const std::int32_t body =
                 (split.tail_block - split.first_block) * split.parts;
@@ -323,6 +424,44 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     ACCBLAS_TRSV_WIDE_STAMP(12);  // ticket drawn
     const index_type block = shared_block;
     const std::uint32_t epoch = shared_epoch;
+    // what every workgroup does last (see the end of the kernel)
+    const auto finish = [&]() __attribute__((always_inline)) {
+        // ---- re-arm the workspace for the next solve (as `kernel::trsv`) -------
+        // (`front` was last raised by this block's poller, long before this block
+        // counts as finished)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            drain_vmem();  // this thread's raise of `front` has been performed
+            const unsigned int done = __hip_atomic_fetch_add(
+                &session.state->finished, 1u, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+            is_last = done == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (is_last) {
+            std::uint32_t next_epoch = epoch + 1;
+            if (next_epoch == 0) {
+                for (index_type i = threadIdx.x; i < session.capacity_words;
+                     i += blockDim.x) {
+                    __hip_atomic_store(granules + i, granule_word{0},
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                next_epoch = trsv_first_epoch;
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                detail::rearm_state(session.state, next_epoch);
+            }
+        }
+    };
+    if (block == detail::trsv_wide_prefetch_block) {
+        detail::prefetch_ahead<Upper, R>(mtx_traits::data(mtx),
+                                         mtx_traits::stride(mtx), n,
+                                         session.state, helper, shared_part,
+                                         split.prefetchers);
+        finish();
+        return;
+    }
     const index_type base = block * R;
     if (base >= n) {
         return;  // cannot happen: the grid covers exactly ceil(n / R) blocks
@@ -1096,33 +1235,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     }
 #endif
 
-    // ---- re-arm the workspace for the next solve (as `kernel::trsv`) -------
-    // (`front` was last raised by this block's poller, long before this block
-    // counts as finished)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        drain_vmem();  // this thread's raise of `front` has been performed
-        const unsigned int done = __hip_atomic_fetch_add(
-            &session.state->finished, 1u, __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT);
-        is_last = done == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (is_last) {
-        std::uint32_t next_epoch = epoch + 1;
-        if (next_epoch == 0) {
-            for (index_type i = threadIdx.x; i < session.capacity_words;
-                 i += blockDim.x) {
-                __hip_atomic_store(granules + i, granule_word{0},
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            next_epoch = trsv_first_epoch;
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            detail::rearm_state(session.state, next_epoch);
-        }
-    }
+    finish();
 }
 
 
@@ -1240,11 +1353,12 @@ inline trsv_wide_split trsv_wide_split_for(index_type n, int num_cus,
                                ACCBLAS_TRSV_WIDE_TAIL_PARTS,
                                ACCBLAS_TRSV_WIDE_TAIL_DEFERRED,
                                blocks - last_blocks,
-                               last_blocks > 0 ? ACCBLAS_TRSV_WIDE_LAST_PARTS : 1};
+                               last_blocks > 0 ? ACCBLAS_TRSV_WIDE_LAST_PARTS : 1,
+                               0};
     }
     return trsv_wide_split{blocks, 1, blocks, 1,
                            static_cast<int>(trsv_wide_deferred_columns), blocks,
-                           1};
+                           1, 0};
 }
 
 /** Workgroups a solve launches under `split`. */
@@ -1254,7 +1368,7 @@ inline unsigned trsv_wide_grid(index_type n, const trsv_wide_split &split)
     return static_cast<unsigned>(
         split.first_block + (split.tail_block - split.first_block) * split.parts +
         (split.last_block - split.tail_block) * split.tail_parts +
-        (blocks - split.last_block) * split.last_parts);
+        (blocks - split.last_block) * split.last_parts + split.prefetchers);
 }
 
 /** The 128-row kernel under an explicit `split` (tools; the library goes
@@ -1283,7 +1397,7 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
     if (split.parts > trsv_wide_max_parts ||
         split.tail_parts > trsv_wide_max_parts || split.parts < 1 ||
         split.tail_parts < 1 || split.last_parts > trsv_wide_max_parts ||
-        split.last_parts < 1 ||
+        split.last_parts < 1 || split.prefetchers < 0 ||
         split.last_block > ceildiv(n, index_type{trsv_wide_rows}) ||
         split.last_block < split.tail_block) {
         return hipErrorInvalidValue;
@@ -1342,15 +1456,43 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
     return hipGetLastError();
 }
 
+/** Prefetching workgroups a solve gets (`trsv_wide_split::prefetchers`):
+ *  the CUs the row blocks leave idle, up to 128 of them, where it was measured
+ *  to pay - 4- and 8-byte storage, 32 to 144 row blocks (n = 4096 ... 18432),
+ *  see `detail::prefetch_ahead`; with 2-byte storage, whose followers wait for
+ *  the front and not for their tiles, they cost 5 %. `mode`: 0 never, 1 by
+ *  that rule, 2 whenever CUs are idle (measurements). */
+template <typename StType>
+inline int trsv_wide_prefetchers_for(index_type n, int num_cus, int mode)
+{
+    const int blocks = static_cast<int>(ceildiv(n, index_type{trsv_wide_rows}));
+    const int spare = num_cus - blocks;
+    if (mode == 0 || spare <= 0) {
+        return 0;
+    }
+    if (mode == 1 && (sizeof(StType) < 4 || blocks < 32 || blocks > 144)) {
+        return 0;
+    }
+    return spare < 128 ? spare : 128;
+}
+
 template <typename ArType, typename MtxView, typename XView>
 hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
                             const XView &x, std::uint32_t *helper,
                             const trsv_session &session, hipStream_t stream,
-                            int num_cus, int split_from = 0)
+                            int num_cus, int split_from = 0,
+                            int prefetch_mode = 1)
 {
-    return launch_trsv_wide_split<ArType>(
-        upper, unit_diag, mtx, x, helper, session, stream,
-        trsv_wide_split_for(mtx.length(0), num_cus, split_from));
+    using st_type =
+        std::remove_cv_t<typename view_traits<XView>::storage_type>;
+    trsv_wide_split split =
+        trsv_wide_split_for(mtx.length(0), num_cus, split_from);
+    split.prefetchers =
+        split.parts == 1 ? trsv_wide_prefetchers_for<st_type>(
+                               mtx.length(0), num_cus, prefetch_mode)
+                         : 0;
+    return launch_trsv_wide_split<ArType>(upper, unit_diag, mtx, x, helper,
+                                          session, stream, split);
 }
 
 

@@ -84,8 +84,8 @@ size_t accblas_dtype_size(accblas_dtype t);
  * compile-time constants). The knobs take 0, 1 or 2 unless said otherwise.
  * Known names:
  *   "trsv_wide"   1 (default) = systems with n >= 4096 (8-byte storage:
- *                 n >= 16384) and a 16-byte aligned matrix base and row
- *                 stride use 128-row blocks
+ *                 4096 <= n < 17000 or n > 32768) and a 16-byte aligned
+ *                 matrix base and row stride use 128-row blocks
  *                 (`kernel::trsv_wide`: half as many dependent hops through
  *                 memory, the folded panel held in registers), everything
  *                 else 64-row blocks (`kernel::trsv`); 0 = 64-row blocks only;
@@ -106,6 +106,13 @@ size_t accblas_dtype_size(accblas_dtype t);
  *                 columns, the owner adds their sums in a fixed order);
  *                 0 (default) = that rule, k > 0 = from row block k on (at
  *                 least 98).
+ *   "trsv_prefetch"  128-row kernel: 1 (default) = solves of 4- or 8-byte
+ *                 storage with 32 to 144 row blocks (n = 4096 ... 18432) launch extra
+ *                 workgroups on the CUs the row blocks leave idle, which pull
+ *                 the tiles of the next block columns into the Infinity Cache
+ *                 ahead of the chain's front (4-byte storage 3-6 % faster,
+ *                 8-byte 12-26 %; same bits);
+ *                 0 = never; 2 = whenever CUs are idle.
  * Unknown names and other values return ACCBLAS_ERR_INVALID_ARGUMENT. */
 int accblas_set_option(const char *name, int value);
 

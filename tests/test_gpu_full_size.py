@@ -259,6 +259,40 @@ def test_trsv_split_row_blocks_match_oracle_and_unsplit_bits(gpu, ar, st, unit, 
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
 
 
+@pytest.mark.parametrize("upper", [False, True])
+@pytest.mark.parametrize("ar,st,n", [(F64, F32, 8200), (F32, F16, 5000), (F64, F64, 4104), (F64, F32, 300)])
+def test_trsv_prefetching_workgroups_do_not_change_a_bit(gpu, upper, ar, st, n):
+    """Option "trsv_prefetch": the workgroups beyond the row blocks only touch
+    the matrix ahead of the chain's front (option 2 = whenever CUs are idle, for
+    every storage type and size); the solution must be the bits of a solve
+    without them, the ragged last row block and the upper triangle's mirrored
+    addressing included, and the workspace must come back re-armed (two solves
+    in a row)."""
+    torch, accblas = gpu
+    lda = n + 8
+    rng = np.random.default_rng(81)
+    full = rng.uniform(-1.0, 1.0, (n, lda)) / np.sqrt(n)
+    A = torch.from_numpy(oracle.convert(full.reshape(-1), st)).cuda()
+    b = oracle.convert(rng.uniform(-1.0, 1.0, n), st)
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    uplo = accblas.UPPER if upper else accblas.LOWER
+    got = {}
+    accblas.set_option("trsv_wide", 2)
+    try:
+        for mode in (0, 2, 2, 1):
+            accblas.set_option("trsv_prefetch", mode)
+            dx = torch.from_numpy(b).cuda()
+            accblas.acc_trsv(ar, st, uplo, accblas.UNIT, n, A, lda, dx, 1, helper)
+            torch.cuda.synchronize()
+            assert int(helper[0].item()) & 0xffffffff == 0xffffffff
+            got.setdefault(mode, []).append(dx)
+    finally:
+        accblas.set_option("trsv_wide", 1)
+        accblas.set_option("trsv_prefetch", 1)
+    assert torch.equal(got[0][0], got[2][0]) and torch.equal(got[0][0], got[2][1])
+    assert torch.equal(got[0][0], got[1][0])
+
+
 @pytest.mark.parametrize("wide", [0, 2])
 @pytest.mark.parametrize("upper", [False, True])
 @pytest.mark.parametrize("unit", [True, False])

@@ -5,7 +5,9 @@ processes on one box, differ by up to 4 % at times - more than most changes).
 Acc<fp64, st>, lower / unit; min and median of `reps` event-timed solves per
 build and size (x restored by a device copy inside the timed region, the
 copy's own time subtracted).
-usage: trsv_lib_ab2.py st reps lib_dir[,lib_dir...] [sizes...]   (lib_dir under accessor-blas_amd/)"""
+usage: trsv_lib_ab2.py st reps lib_dir[,lib_dir...] [sizes...]   (lib_dir under accessor-blas_amd/;
+lib_dir:option=value sets an accblas option in that build - options are per loaded file, so two
+settings of one build need two copies of its directory)"""
 import ctypes
 import os
 import statistics
@@ -24,7 +26,13 @@ st, st_torch = ST[st_name]
 i64, vp = ctypes.c_int64, ctypes.c_void_p
 libs = []
 for name in names:
-    lib = ctypes.CDLL(os.path.join(REPO, "accessor-blas_amd", name, "libaccblas_hip.so"))
+    directory, _, setting = name.partition(":")
+    lib = ctypes.CDLL(os.path.join(REPO, "accessor-blas_amd", directory, "libaccblas_hip.so"))
+    for one in filter(None, setting.split("+")):  # option=value[+option=value...]
+        option, _, value = one.partition("=")
+        lib.accblas_set_option.restype = ctypes.c_int
+        lib.accblas_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        assert lib.accblas_set_option(option.encode(), int(value)) == 0, one
     lib.accblas_acc_trsv.restype = ctypes.c_int
     lib.accblas_acc_trsv.argtypes = [ctypes.c_int] * 4 + [i64, vp, i64, vp, i64, vp, vp]
     libs.append(lib)
