@@ -1226,10 +1226,13 @@ constexpr int trsv_partial_slots = ACCBLAS_TRSV_PARTIAL_SLOTS;
 template <typename St>
 constexpr std::size_t trsv_workspace_bytes(index_type n)
 {
+    // (an upper solve of the 128-row kernel is laid out for up to 63 virtual
+    // unknowns in front of the real ones, `trsv_wide_virtual_pad`)
+    const index_type laid_out = n + 64;
     const index_type x_words =
-        ceildiv(n * trsv_granule_words<St>(), index_type{64}) * 64;
+        ceildiv(laid_out * trsv_granule_words<St>(), index_type{64}) * 64;
     const index_type partial_words =
-        ceildiv(n, index_type{128}) * trsv_partial_slots * 128 * 2;
+        ceildiv(laid_out, index_type{128}) * trsv_partial_slots * 128 * 2;
     return static_cast<std::size_t>(x_words + partial_words) *
            sizeof(granule_word);
 }

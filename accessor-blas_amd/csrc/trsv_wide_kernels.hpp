@@ -54,6 +54,23 @@ constexpr int trsv_wide_waves = 8;
 #endif
 constexpr index_type trsv_wide_deferred_columns = ACCBLAS_TRSV_WIDE_DEFERRED;
 
+/** Upper solves run as lower solves on the mirrored index l -> n - 1 - l. A
+ *  tile row of 128 logical columns then starts at memory column n - 128 (c + 1):
+ *  on a cache-line boundary only when n is a multiple of 128 bytes of storage,
+ *  otherwise every tile row lies across one more line (the CLI's default upper
+ *  sweep, n = 100, 200, ...: 12100 took 208 us where 12000 took 180). So the
+ *  mirror is taken around a virtual size n + pad that IS such a multiple: the
+ *  first `pad` logical unknowns do not exist (identity rows, right-hand side
+ *  0; their x = 0 is handed on like any other, nothing is loaded or stored for
+ *  them), every tile is aligned, and the row blocks are those of the virtual
+ *  size. */
+template <typename StType>
+constexpr index_type trsv_wide_virtual_pad(bool upper, index_type n)
+{
+    constexpr index_type line = 128 / static_cast<index_type>(sizeof(StType));
+    return upper ? (line - n % line) % line : index_type{0};
+}
+
 /** Row blocks from `first_block` on are worked on by `parts` workgroups each
  *  (see `kernel::trsv_wide`); parts == 1 switches the splitting off. */
 struct trsv_wide_split {
@@ -367,7 +384,18 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     ACCBLAS_TRSV_WIDE_STAMP(0);  // kernel entry
     const int fi = lane & 15;  // MFMA fragment row (A) / column (B, D)
     const int fk = lane >> 4;  // MFMA fragment k / lane group of a W row
-    const index_type n = mtx.length(0);
+    // `n` = the size the blocks are laid out for (upper: `pad` virtual unknowns
+    // in front, see `trsv_wide_virtual_pad`); logical index l exists if
+    // pad <= l < n
+    const index_type pad =
+        trsv_wide_virtual_pad<st_type>(Upper, mtx.length(0));
+    const index_type n = mtx.length(0) + pad;
+    const auto exists = [pad, n](index_type logical) {
+        return logical >= pad && logical < n;
+    };
+    const auto inside = [pad, n](index_type logical) {
+        return logical < pad ? pad : (logical < n ? logical : n - 1);
+    };
     granule_word *const granules = session.granules;
 
     if (threadIdx.x == 0) {
@@ -502,7 +530,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     st_type own_raw{};
     if (!helper_part) {
         const index_type row = base + threadIdx.x % R;
-        own_raw = x_data[phys(row < n ? row : n - 1) * x_inc];
+        own_raw = x_data[phys(inside(row)) * x_inc];
     }
 
     // ---- stage D00, D11, D10 (a wave reads one tile row per load) ----------
@@ -515,7 +543,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         constexpr int RS = H / Waves;  // tile rows a wave stages
         st_type raw00[RS], raw11[RS], raw10[RS];
         const auto clamped = [&](index_type logical) {
-            return phys(logical < n ? logical : n - 1);
+            return phys(inside(logical));
         };
         const index_type col0 = clamped(base + lane);
         const index_type col1 = clamped(base + H + lane);
@@ -531,21 +559,29 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
             const int r = wave_u + i * Waves;
-            const auto diag_entry = [&](index_type gr, st_type raw) {
+            // (gr, gc = row and column of the entry; what does not exist is an
+            // identity row / a zero)
+            const auto diag_entry = [&](index_type gr, index_type gc,
+                                        st_type raw) {
                 if (lane == r) {
-                    return (UnitDiag || gr >= n) ? ar_type{1} : ar_type(raw);
+                    return (UnitDiag || !exists(gr)) ? ar_type{1} : ar_type(raw);
                 }
-                return (lane < r && gr < n) ? ar_type(raw) : ar_type{};
+                return (lane < r && exists(gr) && exists(gc)) ? ar_type(raw)
+                                                              : ar_type{};
             };
-            tiles[0][r * ld + lane] = diag_entry(base + r, raw00[i]);
-            tiles[1][r * ld + lane] = diag_entry(base + H + r, raw11[i]);
+            tiles[0][r * ld + lane] =
+                diag_entry(base + r, base + lane, raw00[i]);
+            tiles[1][r * ld + lane] =
+                diag_entry(base + H + r, base + H + lane, raw11[i]);
             tiles[2][r * ld + lane] =
-                base + H + r < n ? ar_type(raw10[i]) : ar_type{};
+                exists(base + H + r) && exists(base + lane)
+                    ? ar_type(raw10[i])
+                    : ar_type{};
         }
     }
     if (!helper_part && threadIdx.x < R) {
         own_lds[threadIdx.x] =
-            base + threadIdx.x < n ? ar_type(own_raw) : ar_type{};
+            exists(base + threadIdx.x) ? ar_type(own_raw) : ar_type{};
     }
     __syncthreads();
     ACCBLAS_TRSV_WIDE_STAMP(13);  // tiles staged
@@ -648,7 +684,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const index_type gr = base + kp + q * 4 + fk;
-                const index_type row = phys(gr < n ? gr : n - 1);
+                const index_type row = phys(inside(gr));
 #pragma unroll
                 for (int tj = 0; tj < R / 16; ++tj) {
                     // rows that do not exist are masked below
@@ -809,13 +845,16 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const index_type gr = base + wave_u * RW + k * RPI + row_in_inst;
-        row_ptr[k] = a_data + phys(gr < n ? gr : n - 1) * lda;
+        row_ptr[k] = a_data + phys(inside(gr)) * lda;
     }
     const auto issue = [&](index_type cb, stage &s) {
         const index_type first_col = cb * PanelCols + col_group * Vec;
         // lowest memory column of the group (columns descend for Upper)
+        // (upper: the virtual columns in front - whole vectors, pad and n are
+        // multiples of Vec - read the first real ones instead; their x is 0)
         const index_type mem_col =
-            Upper ? n - 1 - (first_col + Vec - 1) : first_col;
+            Upper ? n - 1 - ((first_col < pad ? pad : first_col) + Vec - 1)
+                  : first_col;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const auto v = load_packed<Vec, true>(row_ptr[k] + mem_col);
@@ -1111,7 +1150,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         const ar_type total = transpose_reduce_sum<NI, LPR>(acc, lane);
         if (col_group < NI) {
             const int r = wave_u * RW + col_group * RPI + row_in_inst;
-            rhs_lds[r] = (base + r < n) ? own_lds[r] - total : ar_type{};
+            rhs_lds[r] = exists(base + r) ? own_lds[r] - total : ar_type{};
         }
     }
     ACCBLAS_TRSV_WIDE_STAMP(3);  // this wave's far sums reduced
@@ -1206,9 +1245,13 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     {
         const index_type own_row = base + own_tile_row;
         if (fk == 0 && own_row < n) {
+            // (virtual unknowns of an upper solve: handed on - x = 0 -, not
+            // stored)
             const st_type solution = static_cast<st_type>(solution_value);
             io::publish(granules, own_row, solution, epoch);  // hand-off first
-            x_data[phys(own_row) * x_inc] = solution;         // the user's vector
+            if (own_row >= pad) {
+                x_data[phys(own_row) * x_inc] = solution;  // the user's vector
+            }
         }
     }
     ACCBLAS_TRSV_WIDE_STAMP(9);  // published
@@ -1390,10 +1433,12 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
                       ACCBLAS_TRSV_WIDE_TAIL_PARTS <= trsv_wide_max_parts &&
                       ACCBLAS_TRSV_WIDE_LAST_PARTS <= trsv_wide_max_parts,
                   "too many parts");
-    const index_type n = mtx.length(0);
-    if (n <= 0) {
+    if (mtx.length(0) <= 0) {
         return hipSuccess;
     }
+    // (the size the row blocks are laid out for, `trsv_wide_virtual_pad`)
+    const index_type n =
+        mtx.length(0) + trsv_wide_virtual_pad<st_type>(upper, mtx.length(0));
     if (split.parts > trsv_wide_max_parts ||
         split.tail_parts > trsv_wide_max_parts || split.parts < 1 ||
         split.tail_parts < 1 || split.last_parts > trsv_wide_max_parts ||
@@ -1485,11 +1530,12 @@ hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
 {
     using st_type =
         std::remove_cv_t<typename view_traits<XView>::storage_type>;
-    trsv_wide_split split =
-        trsv_wide_split_for(mtx.length(0), num_cus, split_from);
+    const index_type laid_out =
+        mtx.length(0) + trsv_wide_virtual_pad<st_type>(upper, mtx.length(0));
+    trsv_wide_split split = trsv_wide_split_for(laid_out, num_cus, split_from);
     split.prefetchers =
         split.parts == 1 ? trsv_wide_prefetchers_for<st_type>(
-                               mtx.length(0), num_cus, prefetch_mode)
+                               laid_out, num_cus, prefetch_mode)
                          : 0;
     return launch_trsv_wide_split<ArType>(upper, unit_diag, mtx, x, helper,
                                           session, stream, split);

@@ -2,7 +2,7 @@
 """Developer A/B (GPU box): acc_trsv of SEVERAL builds of libaccblas_hip.so in
 ONE process on the same buffers, solve by solve in rotating order (boxes, and
 processes on one box, differ by up to 4 % at times - more than most changes).
-Acc<fp64, st>, lower / unit; min and median of `reps` event-timed solves per
+Acc<fp64, st>, lower (UPLO=upper in the environment: upper) / unit; min and median of `reps` event-timed solves per
 build and size (x restored by a device copy inside the timed region, the
 copy's own time subtracted).
 usage: trsv_lib_ab2.py st reps lib_dir[,lib_dir...] [sizes...]   (lib_dir under accessor-blas_amd/;
@@ -17,7 +17,8 @@ import torch
 
 REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 ST = {"f16": (0, torch.float16), "f32": (1, torch.float32), "f64": (2, torch.float64)}
-F64, LOWER, UNIT = 2, 1, 1
+F64, UNIT = 2, 1
+UPLO = 0 if os.environ.get("UPLO", "lower") == "upper" else 1  # accblas_uplo
 
 st_name, reps = sys.argv[1], int(sys.argv[2])
 names = sys.argv[3].split(",")
@@ -37,10 +38,11 @@ for name in names:
     lib.accblas_acc_trsv.argtypes = [ctypes.c_int] * 4 + [i64, vp, i64, vp, i64, vp, vp]
     libs.append(lib)
 helper = torch.zeros(2, dtype=torch.int32, device="cuda")
-print(f"st={st_name} reps={reps}; per build: min / median us", flush=True)
+print(f"st={st_name} {'upper' if UPLO == 0 else 'lower'} reps={reps}; per build: min / median us", flush=True)
 for n in sizes:
     scale = 1.0 / n ** 0.5
-    A = torch.rand(n * n, dtype=torch.float32, device="cuda").mul_(2 * scale).sub_(scale).to(st_torch)
+    lda = max(n, int(os.environ.get("LDA", "0")))  # (LDA in the environment: row stride, as the CLIs' sweeps have it)
+    A = torch.rand(n * lda, dtype=torch.float32, device="cuda").mul_(2 * scale).sub_(scale).to(st_torch)
     x0 = torch.rand(n, dtype=torch.float32, device="cuda").mul_(2).sub_(1).to(st_torch)
     x = x0.clone()
 
@@ -54,7 +56,7 @@ for n in sizes:
 
     def solve(lib):
         x.copy_(x0)
-        rc = lib.accblas_acc_trsv(F64, st, LOWER, UNIT, n, A.data_ptr(), n, x.data_ptr(), 1,
+        rc = lib.accblas_acc_trsv(F64, st, UPLO, UNIT, n, A.data_ptr(), lda, x.data_ptr(), 1,
                                   helper.data_ptr(), None)
         assert rc == 0, rc
     t_copy = min(timed(lambda: x.copy_(x0)) for _ in range(8))
