@@ -49,6 +49,11 @@
 //     per-wave partials combined through LDS, one barrier).
 #pragma once
 
+// (matrix loads of the TRSV kernels: non-temporal unless a build says otherwise)
+#ifndef ACCBLAS_TRSV_NT
+#define ACCBLAS_TRSV_NT true
+#endif
+
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -935,7 +940,7 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             if (Vec > 1) {
-                const auto v = load_packed<(Vec > 1 ? Vec : 2), true>(
+                const auto v = load_packed<(Vec > 1 ? Vec : 2), ACCBLAS_TRSV_NT>(
                     row_ptr[k] + mem_col);
 #pragma unroll
                 for (int e = 0; e < Vec; ++e) {

@@ -35,6 +35,11 @@
 //     arithmetic type, one transposing cross-lane reduction at the end.
 #pragma once
 
+// (matrix loads of the TRSV kernels: non-temporal unless a build says otherwise)
+#ifndef ACCBLAS_TRSV_NT
+#define ACCBLAS_TRSV_NT true
+#endif
+
 #include <hip/hip_runtime.h>
 
 #include "trsv_kernels.hpp"
@@ -857,7 +862,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                   : first_col;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
-            const auto v = load_packed<Vec, true>(row_ptr[k] + mem_col);
+            const auto v = load_packed<Vec, ACCBLAS_TRSV_NT>(row_ptr[k] + mem_col);
 #pragma unroll
             for (int e = 0; e < Vec; ++e) {
                 s.a[k][e] = v[e];
