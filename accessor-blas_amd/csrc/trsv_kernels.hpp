@@ -177,6 +177,24 @@ inline std::uint32_t trsv_next_serial()
 }
 
 
+/** Upper solves run as lower solves on the mirrored index l -> n - 1 - l. A
+ *  tile row of logical columns [c, c + w) then starts at memory column
+ *  n - c - w: on a cache-line boundary only when n is a multiple of 128 bytes
+ *  of storage, otherwise every tile row lies across one more line (the CLI's
+ *  default upper sweep, n = 100, 200, ...: 12100 took 208 us where 12000 took
+ *  180). So the vector paths of both kernels take the mirror around a virtual
+ *  size n + pad that IS such a multiple: the first `pad` logical unknowns do
+ *  not exist (identity rows, right-hand side 0; their x = 0 is handed on like
+ *  any other, nothing is loaded or stored for them), every tile is aligned,
+ *  and the row blocks are those of the virtual size. */
+template <typename StType>
+constexpr index_type trsv_virtual_pad(bool upper, index_type n)
+{
+    constexpr index_type line = 128 / static_cast<index_type>(sizeof(StType));
+    return upper ? (line - n % line) % line : index_type{0};
+}
+
+
 namespace kernel {
 
 
@@ -716,7 +734,19 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     // it feeds the solutions of earlier blocks into LDS for the far sweep
     // (see there) and otherwise only takes part in the barriers
     const bool worker = !Relay || wave < Waves;
-    const index_type n = mtx.length(0);
+    // `n` = the size the blocks are laid out for (vector path of an upper
+    // solve: `pad` virtual unknowns in front, see `trsv_virtual_pad`); logical
+    // index l exists if pad <= l < n
+    const index_type pad =
+        Vec > 1 ? trsv_virtual_pad<st_type>(Upper, mtx.length(0))
+                : index_type{0};
+    const index_type n = mtx.length(0) + pad;
+    const auto exists = [pad, n](index_type logical) {
+        return logical >= pad && logical < n;
+    };
+    const auto inside = [pad, n](index_type logical) {
+        return logical < pad ? pad : (logical < n ? logical : n - 1);
+    };
 
     granule_word *const granules = session.granules;
     __shared__ std::uint32_t shared_epoch;
@@ -768,8 +798,8 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     // this block's right-hand side values (lane = row), never written by
     // another workgroup: plain load, issued early
     const index_type own_row = base + lane;
-    const bool own_valid = own_row < n;
-    st_type *own_addr = x_data + phys(own_valid ? own_row : n - 1) * x_inc;
+    const bool own_valid = exists(own_row);
+    st_type *own_addr = x_data + phys(inside(own_row)) * x_inc;
     const st_type own_raw = *own_addr;  // (clamped address: unconditional)
     const ar_type own_rhs = own_valid ? static_cast<ar_type>(own_raw) : ar_type{};
 
@@ -785,12 +815,13 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
         st_type diag_raw[RS];
         st_type panel_raw[RS];
         const index_type gc = base + lane;
-        const index_type col = phys(gc < n ? gc : n - 1);
-        const index_type panel_col = phys(block > 0 ? base - B + lane : index_type{0});
+        const index_type col = phys(inside(gc));
+        const index_type panel_gc = block > 0 ? base - B + lane : index_type{0};
+        const index_type panel_col = phys(inside(panel_gc));
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
             const index_type gr = base + wave + i * Waves;
-            const st_type *row = a_data + phys(gr < n ? gr : n - 1) * lda;
+            const st_type *row = a_data + phys(inside(gr)) * lda;
             diag_raw[i] = row[col];
             panel_raw[i] = row[panel_col];
         }
@@ -800,16 +831,18 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
             const index_type gr = base + r;
             ar_type diag_value{};
             if (lane == r) {
-                diag_value = (UnitDiag || gr >= n)
+                diag_value = (UnitDiag || !exists(gr))
                                  ? ar_type{1}
                                  : static_cast<ar_type>(diag_raw[i]);
-            } else if (lane < r && gr < n) {
+            } else if (lane < r && exists(gr) && exists(gc)) {
                 diag_value = static_cast<ar_type>(diag_raw[i]);
             }
             tile[r * ld + lane] = diag_value;
             if (block > 0) {
                 panel[lane * ld + r] =
-                    gr < n ? static_cast<ar_type>(panel_raw[i]) : ar_type{};
+                    exists(gr) && exists(panel_gc)
+                        ? static_cast<ar_type>(panel_raw[i])
+                        : ar_type{};
             }
         }
     }
@@ -930,13 +963,16 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const index_type gr = base + wave * RW + k * Vec + row_in_inst;
-        row_ptr[k] = a_data + phys(gr < n ? gr : n - 1) * lda;
+        row_ptr[k] = a_data + phys(inside(gr)) * lda;
     }
     const auto issue = [&](index_type cb, stage &s) {
         const index_type first_col = cb * B + col_group * Vec;  // logical
-        // lowest memory column of the group (columns descend for Upper)
+        // lowest memory column of the group (columns descend for Upper; the
+        // virtual columns in front - whole vectors - read the first real ones
+        // instead: their x is 0)
         const index_type mem_col =
-            Upper ? n - 1 - (first_col + Vec - 1) : first_col;
+            Upper ? n - 1 - ((first_col < pad ? pad : first_col) + Vec - 1)
+                  : first_col;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             if (Vec > 1) {
@@ -1102,7 +1138,7 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
         const ar_type total = transpose_reduce_sum<NI, LPR>(acc, lane);
         if (worker && col_group < NI) {
             const int r = wave * RW + col_group * Vec + row_in_inst;
-            correction[r] = (base + r < n) ? total : ar_type{};
+            correction[r] = exists(base + r) ? total : ar_type{};
         }
     }
     if (wave == 0) {
@@ -1177,9 +1213,13 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
             sum -= detail::tree_sum<Waves>(partial_a, B, lane);
         }
         const st_type solution = static_cast<st_type>(sum);
-        if (own_valid) {
+        if (own_row < n) {
+            // (virtual unknowns of an upper solve: handed on - x = 0 -, not
+            // stored)
             io::publish(granules, own_row, solution, epoch);  // hand-off
-            *own_addr = solution;                       // the user's vector
+            if (own_valid) {
+                *own_addr = solution;  // the user's vector
+            }
         }
         ACCBLAS_TRSV_STAMP(block, 5);  // published
         ACCBLAS_TRSV_CYCLES(block, 12);
@@ -1305,7 +1345,6 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     }
     constexpr int waves = trsv_waves;
     constexpr int vec16 = 16 / sizeof(st_type);
-    const dim3 grid(trsv_num_blocks(n), 1, 1);
     // x through the loader wave and LDS (one more wave per workgroup) where
     // it was measured to pay (profiles/r01_trsv_relay_ab.txt): the granule
     // stream it removes weighs 8 bytes per element and worker, so it wins
@@ -1325,6 +1364,12 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     const bool vec_ok = is_aligned(mtx_traits::data(mtx), 16) &&
                         mtx_traits::stride(mtx) % vec16 == 0 &&
                         (!upper || n % vec16 == 0);
+    // (the vector path of an upper solve is laid out for a virtual size)
+    const dim3 grid(
+        trsv_num_blocks(n + (vec_ok && vec16 > 1
+                                 ? trsv_virtual_pad<st_type>(upper, n)
+                                 : index_type{0})),
+        1, 1);
 #define ACCBLAS_TRSV_LAUNCH_RELAY(_upper, _unit, _relay)                       \
     if (vec_ok) {                                                              \
         kernel::trsv<waves, _upper, _unit, vec16, _relay, ArType>              \

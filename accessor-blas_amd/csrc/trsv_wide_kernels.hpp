@@ -59,21 +59,11 @@ constexpr int trsv_wide_waves = 8;
 #endif
 constexpr index_type trsv_wide_deferred_columns = ACCBLAS_TRSV_WIDE_DEFERRED;
 
-/** Upper solves run as lower solves on the mirrored index l -> n - 1 - l. A
- *  tile row of 128 logical columns then starts at memory column n - 128 (c + 1):
- *  on a cache-line boundary only when n is a multiple of 128 bytes of storage,
- *  otherwise every tile row lies across one more line (the CLI's default upper
- *  sweep, n = 100, 200, ...: 12100 took 208 us where 12000 took 180). So the
- *  mirror is taken around a virtual size n + pad that IS such a multiple: the
- *  first `pad` logical unknowns do not exist (identity rows, right-hand side
- *  0; their x = 0 is handed on like any other, nothing is loaded or stored for
- *  them), every tile is aligned, and the row blocks are those of the virtual
- *  size. */
+/** The virtual unknowns in front of an upper solve (`trsv_virtual_pad`). */
 template <typename StType>
 constexpr index_type trsv_wide_virtual_pad(bool upper, index_type n)
 {
-    constexpr index_type line = 128 / static_cast<index_type>(sizeof(StType));
-    return upper ? (line - n % line) % line : index_type{0};
+    return trsv_virtual_pad<StType>(upper, n);
 }
 
 /** Row blocks from `first_block` on are worked on by `parts` workgroups each
