@@ -965,13 +965,19 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
         const index_type gr = base + wave * RW + k * Vec + row_in_inst;
         row_ptr[k] = a_data + phys(inside(gr)) * lda;
     }
+    // (upper: first logical column from which whole vectors exist)
+    const index_type first_real_vector = ceildiv(pad, index_type{Vec}) * Vec;
     const auto issue = [&](index_type cb, stage &s) {
         const index_type first_col = cb * B + col_group * Vec;  // logical
-        // lowest memory column of the group (columns descend for Upper; the
-        // virtual columns in front - whole vectors - read the first real ones
-        // instead: their x is 0)
+        // lowest memory column of the group (columns descend for Upper;
+        // vectors of virtual columns only read the first vector of real ones
+        // instead - their x is 0 -; the one vector that holds both, when n is
+        // not a multiple of Vec, is cleaned up in `consume`)
         const index_type mem_col =
-            Upper ? n - 1 - ((first_col < pad ? pad : first_col) + Vec - 1)
+            Upper ? n - 1 -
+                        ((first_col + Vec <= pad ? first_real_vector
+                                                 : first_col) +
+                         Vec - 1)
                   : first_col;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
@@ -1035,6 +1041,20 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
 #pragma unroll
             for (int e = 0; e < Vec; ++e) {
                 xv[e] = x_ring[slot][col_group * Vec + e];
+            }
+        }
+        if (Upper && Vec > 1 && cb == 0 && pad % Vec != 0) {
+            // the vector across the first real column: what was loaded for
+            // its virtual columns lies beyond the row's end
+#pragma unroll
+            for (int e = 0; e < Vec; ++e) {
+                if (col_group * Vec + (Vec - 1 - e) < pad &&
+                    col_group * Vec + Vec > pad) {
+#pragma unroll
+                    for (int k = 0; k < NI; ++k) {
+                        s.a[k][e] = st_type{};
+                    }
+                }
             }
         }
 #pragma unroll
@@ -1361,9 +1381,9 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     const dim3 block((waves + (relay ? 1 : 0)) * wave_size, 1, 1);
     const unsigned pad = relay ? trsv_single_block_pad<ArType, waves, true>()
                                : trsv_single_block_pad<ArType, waves, false>();
+    // (upper solves of any n: the vector path mirrors around a virtual size)
     const bool vec_ok = is_aligned(mtx_traits::data(mtx), 16) &&
-                        mtx_traits::stride(mtx) % vec16 == 0 &&
-                        (!upper || n % vec16 == 0);
+                        mtx_traits::stride(mtx) % vec16 == 0;
     // (the vector path of an upper solve is laid out for a virtual size)
     const dim3 grid(
         trsv_num_blocks(n + (vec_ok && vec16 > 1

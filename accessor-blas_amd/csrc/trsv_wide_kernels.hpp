@@ -842,13 +842,19 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         const index_type gr = base + wave_u * RW + k * RPI + row_in_inst;
         row_ptr[k] = a_data + phys(inside(gr)) * lda;
     }
+    // (upper: first logical column from which whole vectors exist)
+    const index_type first_real_vector = ceildiv(pad, index_type{Vec}) * Vec;
     const auto issue = [&](index_type cb, stage &s) {
         const index_type first_col = cb * PanelCols + col_group * Vec;
         // lowest memory column of the group (columns descend for Upper)
-        // (upper: the virtual columns in front - whole vectors, pad and n are
-        // multiples of Vec - read the first real ones instead; their x is 0)
+        // (upper: vectors of virtual columns only read the first vector of
+        // real ones instead - their x is 0 -; the one vector that holds
+        // both, when n is not a multiple of Vec, is cleaned up in `consume`)
         const index_type mem_col =
-            Upper ? n - 1 - ((first_col < pad ? pad : first_col) + Vec - 1)
+            Upper ? n - 1 -
+                        ((first_col + Vec <= pad ? first_real_vector
+                                                 : first_col) +
+                         Vec - 1)
                   : first_col;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
@@ -962,6 +968,21 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     const auto consume = [&](index_type cb, stage &s) {
         if (cb == chunk_end_step) {
             next_chunk();
+        }
+        if (Upper && cb == 0 && pad % Vec != 0) {
+            // the vector across the first real column: what was loaded for
+            // its virtual columns lies beyond the row's end
+#pragma unroll
+            for (int e = 0; e < Vec; ++e) {
+                // (memory element e = logical column Vec-1-e of the group)
+                if (col_group * Vec + (Vec - 1 - e) < pad &&
+                    col_group * Vec + Vec > pad) {
+#pragma unroll
+                    for (int k = 0; k < NI; ++k) {
+                        s.a[k][e] = st_type{};
+                    }
+                }
+            }
         }
         const int offset = static_cast<int>(cb / PPB - chunk_first) * R +
                            static_cast<int>(cb % PPB) * PanelCols +
@@ -1297,16 +1318,16 @@ constexpr unsigned trsv_wide_single_block_pad()
 
 
 /** Operands the 128-row kernel takes: 16-byte aligned matrix base and row
- *  stride, and for upper solves n a multiple of the vector length. */
+ *  stride. */
 template <typename MtxView>
 bool trsv_wide_applicable(bool upper, const MtxView &mtx)
 {
     using mtx_traits = view_traits<MtxView>;
     using st_type = std::remove_cv_t<typename mtx_traits::storage_type>;
     constexpr int vec16 = 16 / sizeof(st_type);
+    (void)upper;  // (upper solves of any n: mirrored around a virtual size)
     return is_aligned(mtx_traits::data(mtx), 16) &&
-           mtx_traits::stride(mtx) % vec16 == 0 &&
-           (!upper || mtx.length(0) % vec16 == 0);
+           mtx_traits::stride(mtx) % vec16 == 0;
 }
 
 

@@ -368,7 +368,10 @@ def _triangular_system(n, lda, upper, seed):
 
 
 TRSV_SIZES = [(1, 1), (31, 40), (64, 64), (65, 100), (100, 24000 // 8), (128, 128),
-              (200, 256), (264, 264), (1000, 1000), (2050, 2112)]
+              (200, 256), (264, 264), (1000, 1000), (2050, 2112),
+              # n off the vector length with a row stride the vector paths take:
+              # an upper solve then has a vector across its first real column
+              (267, 272), (1001, 1008), (2051, 2112)]
 
 
 @pytest.mark.parametrize("trsv_kernel", list(KERNELS), indirect=True)
