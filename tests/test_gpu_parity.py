@@ -371,7 +371,10 @@ TRSV_SIZES = [(1, 1), (31, 40), (64, 64), (65, 100), (100, 24000 // 8), (128, 12
               (200, 256), (264, 264), (1000, 1000), (2050, 2112),
               # n off the vector length with a row stride the vector paths take:
               # an upper solve then has a vector across its first real column
-              (267, 272), (1001, 1008), (2051, 2112)]
+              (267, 272), (1001, 1008), (2051, 2112),
+              # packed matrices whose row stride is off the vector length (the
+              # 64-row kernel's scalar path; 8-byte vectors were measured: no gain)
+              (270, 270), (1002, 1002), (1004, 1004)]
 
 
 @pytest.mark.parametrize("trsv_kernel", list(KERNELS), indirect=True)
