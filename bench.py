@@ -127,9 +127,27 @@ def launch_ranks(world, argv, command=None, timeout=None, poll=0.05):
     # the result line counts only when every rank finished; what rank 0 had
     # printed before a failure goes to stderr
     outputs[0].seek(0)
-    target = sys.stdout if status == 0 else sys.stderr
-    target.write(outputs[0].read())
-    target.flush()
+    text = outputs[0].read()
+    if isinstance(text, bytes):
+        text = text.decode(errors="replace")
+    if status == 0:
+        # stdout carries the result line and nothing else: what libraries of a
+        # rank wrote there besides ("[Gloo] Rank 0 is connected to ...") goes
+        # to stderr
+        lines = text.splitlines()
+        result = [line for line in lines if line.startswith("{")]
+        for line in lines:
+            if not line.startswith("{"):
+                print(line, file=sys.stderr)
+        if result:
+            sys.stdout.write(result[-1] + "\n")
+        else:
+            print("bench.py: rank 0 printed no result line", file=sys.stderr)
+            status = 1
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(text)
+        sys.stderr.flush()
     for out in outputs:
         out.close()
     return status

@@ -36,12 +36,25 @@ def test_all_ranks_succeed_and_rank0_line_is_relayed(tmp_path, capfd):
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
         assert os.environ["LOCAL_RANK"] == os.environ["RANK"]
-        print(f"rank {rank} of {world} args {sys.argv[1:]}")
+        print("[Gloo] Rank is connected: library chatter on stdout")
+        print('{"rank": %d, "world": %d, "args": "%s"}' % (rank, world, " ".join(sys.argv[1:])))
     """)
     status = bench.launch_ranks(3, ["--gpus", "3"], command=cmd, timeout=60)
-    out = capfd.readouterr().out
+    captured = capfd.readouterr()
     assert status == 0
-    assert out == "rank 0 of 3 args ['--gpus', '3']\n"
+    # stdout carries rank 0's result line and nothing else
+    assert captured.out == '{"rank": 0, "world": 3, "args": "--gpus 3"}\n'
+    assert "[Gloo]" in captured.err
+
+
+def test_ranks_that_print_no_result_line_fail_the_parent(tmp_path, capfd):
+    cmd = _script(tmp_path, """
+        print("no result here")
+    """)
+    status = bench.launch_ranks(2, ["--gpus", "2"], command=cmd, timeout=60)
+    captured = capfd.readouterr()
+    assert status != 0
+    assert captured.out == ""
 
 
 def test_one_failed_rank_stops_the_others_and_fails_the_parent(tmp_path, capfd):
