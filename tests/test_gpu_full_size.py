@@ -293,6 +293,39 @@ def test_trsv_prefetching_workgroups_do_not_change_a_bit(gpu, upper, ar, st, n):
     assert torch.equal(got[0][0], got[1][0])
 
 
+def test_trsv_with_prefetchers_beside_other_kernels(gpu):
+    """Solves that launch prefetching workgroups (n = 8192: 64 row blocks, 128
+    prefetchers) on one stream, large GEMVs on a second and upper solves of an
+    n off the vector length on a third: the CUs the prefetchers count on are
+    taken at times, nothing may hang or change a bit."""
+    torch, accblas = gpu
+    n = 8192
+    A = (torch.rand(n * n, device="cuda") * 2 - 1) / n ** 0.5
+    x0 = torch.rand(n, device="cuda") * 2 - 1
+    G = torch.rand(8192 * 8192, device="cuda")
+    gx, gy = torch.rand(8192, device="cuda"), torch.zeros(8192, device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    ha = torch.zeros(2, dtype=torch.int32, device="cuda")
+    hc = torch.zeros(2, dtype=torch.int32, device="cuda")
+    xa, xc, ref, ref_upper = x0.clone(), x0.clone(), x0.clone(), x0.clone()
+    accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, A, n, ref, 1, ha)
+    accblas.acc_trsv(F64, F32, accblas.UPPER, accblas.UNIT, n - 3, A, n, ref_upper, 1, hc)
+    torch.cuda.synchronize()
+    for it in range(100):
+        with torch.cuda.stream(streams[0]):
+            xa.copy_(x0)
+            accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, A, n, xa, 1, ha, streams[0])
+        with torch.cuda.stream(streams[1]):
+            accblas.acc_gemv(F64, F32, 8192, 8192, 1.0, G, 8192, gx, 1, 0.0, gy, 1, streams[1])
+        with torch.cuda.stream(streams[2]):
+            xc.copy_(x0)
+            accblas.acc_trsv(F64, F32, accblas.UPPER, accblas.UNIT, n - 3, A, n, xc, 1, hc, streams[2])
+    torch.cuda.synchronize()
+    assert int(ha[0].item()) & 0xffffffff == 0xffffffff
+    assert int(hc[0].item()) & 0xffffffff == 0xffffffff
+    assert torch.equal(xa, ref) and torch.equal(xc, ref_upper)
+
+
 @pytest.mark.parametrize("wide", [0, 2])
 @pytest.mark.parametrize("upper", [False, True])
 @pytest.mark.parametrize("unit", [True, False])
