@@ -111,4 +111,35 @@ int accblas_acc_dot(accblas_handle *handle, accblas_dtype ar, accblas_dtype st,
 }
 
 
+int accblas_dot_status(accblas_handle *handle, void *stream, int *expired)
+{
+    if (handle == nullptr || expired == nullptr) {
+        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER,
+                                  "dot_status: handle or expired is NULL");
+    }
+    int status = accblas::check_hip(
+        hipStreamSynchronize(accblas::as_stream(stream)),
+        "hipStreamSynchronize");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    std::uint32_t word = 0;
+    status = accblas::check_hip(
+        hipMemcpy(&word, handle->dot_ws.status, sizeof(word),
+                  hipMemcpyDeviceToHost),
+        "hipMemcpy(dot status)");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    *expired = word == accblas::dev::dot_expired_word ? 1 : 0;
+    if (*expired != 0) {
+        // reported once
+        status = accblas::check_hip(
+            hipMemset(handle->dot_ws.status, 0, sizeof(word)),
+            "hipMemset(dot status)");
+    }
+    return status;
+}
+
+
 }  // extern "C"

@@ -15,7 +15,8 @@ struct accblas_handle {
     int device;
     int num_cus;
     accblas_dot_mode dot_mode;
-    // one device allocation: [dot slots | scalar(16 B) | trsv helper(16 B)]
+    // one device allocation: [dot slots | scalar(16 B) | trsv helper(16 B) |
+    // dot status(16 B)]
     void *workspace;
     accblas::dev::dot_workspace dot_ws;
     std::uint32_t *trsv_helper;

@@ -264,7 +264,7 @@ int accblas_handle_create(accblas_handle **handle)
         return status;
     }
     constexpr size_t slot_bytes = accblas::dev::dot_slot_bytes;
-    constexpr size_t total_bytes = slot_bytes + 2 * 16;
+    constexpr size_t total_bytes = slot_bytes + 3 * 16;
     void *workspace = nullptr;
     status = check_hip(hipMalloc(&workspace, total_bytes), "hipMalloc");
     if (status != ACCBLAS_OK) {
@@ -286,6 +286,8 @@ int accblas_handle_create(accblas_handle **handle)
     h->dot_ws.num_cus = h->num_cus;
     h->dot_ws.serial = 1;
     h->trsv_helper = reinterpret_cast<std::uint32_t *>(bytes + slot_bytes + 16);
+    h->dot_ws.status =
+        reinterpret_cast<std::uint32_t *>(bytes + slot_bytes + 32);
     *handle = h;
     return ACCBLAS_OK;
 }

@@ -43,7 +43,12 @@ constexpr std::size_t dot_slot_bytes =
     std::size_t{dot_max_partials} * dot_slot_words * sizeof(dot_slot_word);
 // The collector gives up after this many unsuccessful polls of one slot
 // (seconds; a healthy launch needs microseconds) and returns NaN.
-constexpr unsigned int dot_spin_limit = 1u << 22;
+#ifndef ACCBLAS_DOT_SPIN_LIMIT
+#define ACCBLAS_DOT_SPIN_LIMIT (1u << 22)
+#endif
+constexpr unsigned int dot_spin_limit = ACCBLAS_DOT_SPIN_LIMIT;
+// what the collector leaves in `dot_workspace::status` when it gave up
+constexpr std::uint32_t dot_expired_word = 0xdeadbeefu;
 
 
 namespace detail {
@@ -185,7 +190,7 @@ template <typename Config, int Vec, bool Atomic, typename XView,
           typename YView, typename ArType, typename ResType>
 __global__ __launch_bounds__(Config::waves *wave_size) void dot(
     XView x, YView y, ArType *accum, dot_slot_word *slots,
-    std::uint32_t serial, ResType *res)
+    std::uint32_t serial, ResType *res, std::uint32_t *status)
 {
     constexpr int Waves = Config::waves;
     constexpr int Unroll = Config::unroll;
@@ -334,10 +339,16 @@ __global__ __launch_bounds__(Config::waves *wave_size) void dot(
     total = block_reduce_sum<Waves>(total, scratch);
     const bool any_expired = __syncthreads_or(expired);
     if (threadIdx.x == 0) {
-        // a wait that gave up (cannot happen on a healthy device) must not
-        // look like a result
+        // a wait that gave up (the other workgroups of the grid did not get
+        // a CU for seconds, e.g. behind another stream's kernel) must not
+        // look like a result: NaN, and a sticky word the host can ask for
+        // (`accblas_dot_status`)
         *res = any_expired ? static_cast<ResType>(__builtin_nanf(""))
                            : static_cast<ResType>(total);
+        if (any_expired && status != nullptr) {
+            __hip_atomic_store(status, dot_expired_word, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -349,6 +360,7 @@ __global__ __launch_bounds__(Config::waves *wave_size) void dot(
 struct dot_workspace {
     dot_slot_word *slots;    // dot_slot_bytes: one tagged slot per workgroup
     void *scalar;            // 16-byte slot (`get_device_value_ptr`)
+    std::uint32_t *status = nullptr;  // sticky "a collector gave up" word, or NULL
     int num_cus;
     std::uint32_t serial;    // tag of the NEXT launch (host side, never 0)
 
@@ -409,10 +421,12 @@ hipError_t launch_dot_with(dot_workspace &ws, bool atomic,
         kernel::init_res<<<1, 64, 0, stream>>>(accum);
         if (vec_ok) {
             kernel::dot<Config, vec, true>
-                <<<grid, block, 0, stream>>>(x, y, accum, ws.slots, 0u, res);
+                <<<grid, block, 0, stream>>>(x, y, accum, ws.slots, 0u, res,
+                                             ws.status);
         } else {
             kernel::dot<Config, 1, true>
-                <<<grid, block, 0, stream>>>(x, y, accum, ws.slots, 0u, res);
+                <<<grid, block, 0, stream>>>(x, y, accum, ws.slots, 0u, res,
+                                             ws.status);
         }
         if (!direct) {
             kernel::cast_result<<<1, 64, 0, stream>>>(accum, res);
@@ -422,10 +436,12 @@ hipError_t launch_dot_with(dot_workspace &ws, bool atomic,
         const std::uint32_t serial = ws.next_serial();
         if (vec_ok) {
             kernel::dot<Config, vec, false>
-                <<<grid, block, 0, stream>>>(x, y, unused, ws.slots, serial, res);
+                <<<grid, block, 0, stream>>>(x, y, unused, ws.slots, serial, res,
+                                             ws.status);
         } else {
             kernel::dot<Config, 1, false>
-                <<<grid, block, 0, stream>>>(x, y, unused, ws.slots, serial, res);
+                <<<grid, block, 0, stream>>>(x, y, unused, ws.slots, serial, res,
+                                             ws.status);
         }
     }
     return hipGetLastError();

@@ -246,9 +246,9 @@ struct trsv_ticket {
  * (see `trsv_state`) while the others wait for the re-armed word. Waits are
  * bounded like every other wait of the solve (`spin_expired`).
  */
-__device__ __forceinline__ trsv_ticket draw_ticket(trsv_state *state,
-                                                   std::uint32_t serial,
-                                                   std::uint32_t *helper)
+__device__ __forceinline__ trsv_ticket draw_ticket(
+    trsv_state *state, std::uint32_t serial, std::uint32_t *helper,
+    granule_word *granules, index_type capacity_words)
 {
     using word = unsigned long long;
     const auto key_of = [](word w) { return static_cast<std::uint32_t>(w >> 32); };
@@ -308,6 +308,18 @@ __device__ __forceinline__ trsv_ticket draw_ticket(trsv_state *state,
                                       __HIP_MEMORY_SCOPE_AGENT) +
                     1;
                 epoch = epoch < trsv_first_epoch ? trsv_first_epoch : epoch;
+                // The epoch word of a broken header proves nothing (bytes
+                // written over it may have moved it BACK, all-ones wraps to
+                // the first epoch): hand-off words of an earlier solve could
+                // carry the new tag. So the repairer clears every word, as the
+                // end of a solve does when the epoch wraps. One thread, up to
+                // a few MB of fire-and-forget stores: a millisecond on a path
+                // that only a dead launch or a scribbler leads to.
+                for (index_type i = 0; i < capacity_words; ++i) {
+                    __hip_atomic_store(granules + i, granule_word{0},
+                                       __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
                 __hip_atomic_store(&state->finished, 0u, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&state->front, 0u, __ATOMIC_RELAXED,
@@ -760,7 +772,8 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
         // the previous solve on this workspace finished before this kernel
         // started (stream order), so the epoch is stable for the whole solve
         const detail::trsv_ticket drawn =
-            detail::draw_ticket(session.state, session.serial, helper);
+            detail::draw_ticket(session.state, session.serial, helper,
+                                session.granules, session.capacity_words);
         const unsigned int ticket = drawn.ticket;
         shared_epoch = drawn.epoch;
         // (a ticket that could not be had - ~0u - is out of range: the

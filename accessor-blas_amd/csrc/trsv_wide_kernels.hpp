@@ -148,8 +148,9 @@ constexpr std::int32_t trsv_wide_prefetch_block = 0x3ffffffe;
  * builds alternated in one process): 4096 -3.9 %, 6144 -6.2 %, 12288 -5 %,
  * 16384 -2.5 %; 8-byte storage 4096 -15 %, 8192 -26 %, 16384 -12 % (its
  * tiles are twice as large); 2-byte storage +5 % (not used there). Returns when the front is within three block
- * columns of the end, when another workgroup has given up, or after
- * `trsv_spin_limit` looks at a front that does not move.
+ * columns of the end, when a solver workgroup has given up, or after
+ * `trsv_spin_limit` looks at a front that has not moved meanwhile; it never
+ * writes the error word itself.
  */
 template <bool Upper, int R, typename StType>
 __device__ __forceinline__ void prefetch_ahead(const StType *a_data,
@@ -164,6 +165,7 @@ __device__ __forceinline__ void prefetch_ahead(const StType *a_data,
     const int blocks = static_cast<int>(ceildiv(n, index_type{R}));
     int done = 2;  // block columns below this are taken care of
     unsigned int spins = 0;
+    int last_front = -1;
     std::uint32_t bits = 0;
     while (true) {
         const int front = static_cast<int>(
@@ -176,8 +178,21 @@ __device__ __forceinline__ void prefetch_ahead(const StType *a_data,
                              ? front + 1 + trsv_wide_prefetch_ahead
                              : blocks - 1;
         done = done < front + 1 ? front + 1 : done;  // (what the front has passed)
+        if (front != last_front) {
+            last_front = front;
+            spins = 0;  // the limit is on a front that does not MOVE
+        }
         if (done >= upto) {
-            if (spin_expired(spins, helper)) {
+            // A prefetcher is optional: it leaves when a solver has given up
+            // or when the front has stood still for `trsv_spin_limit` looks,
+            // but it never declares the solve failed (a solve stretched by
+            // other streams' kernels completes without it).
+            ++spins;
+            if (spins >= trsv_spin_limit ||
+                ((spins & 1023u) == 0 &&
+                 __hip_atomic_load(helper, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT) ==
+                     trsv_error_word)) {
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
@@ -395,7 +410,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
 
     if (threadIdx.x == 0) {
         const detail::trsv_ticket drawn =
-            detail::draw_ticket(session.state, session.serial, helper);
+            detail::draw_ticket(session.state, session.serial, helper,
+                                session.granules, session.capacity_words);
         // (a ticket that could not be had - ~0u - maps to a block beyond the
         // matrix: the workgroup leaves, helper[0] says why)
         const unsigned int ticket =

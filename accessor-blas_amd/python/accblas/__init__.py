@@ -81,6 +81,7 @@ SIGNATURES = {
     "accblas_dot": (_int, [_vp, _int, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "accblas_acc_dot": (_int, [_vp, _int, _int, _int, _i64, _vp, _i64, _vp, _i64, _vp,
                                _vp]),
+    "accblas_dot_status": (_int, [_vp, _vp, ctypes.POINTER(_int)]),
     "accblas_trsv": (_int, [_int, _int, _int, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "accblas_acc_trsv": (_int, [_int, _int, _int, _int, _i64, _vp, _i64, _vp, _i64,
                                 _vp, _vp]),
@@ -266,6 +267,14 @@ def acc_dot(handle, ar, st, res_t, n, x, incx, y, incy, res, stream=None):
     """`acc_dot<ArType, StType, ResType>` (`cuda/dot_kernels.cuh:224-263`)."""
     _check(load().accblas_acc_dot(handle.raw, ar, st, res_t, n, _ptr(x), incx, _ptr(y),
                                   incy, _ptr(res), _stream(stream)))
+
+
+def dot_status(handle, stream=None):
+    """True when the collector of a deterministic dot on `handle` gave up since
+    the last call (`accblas_dot_status`; synchronises the stream)."""
+    out = _int()
+    _check(load().accblas_dot_status(handle.raw, _stream(stream), ctypes.byref(out)))
+    return bool(out.value)
 
 
 def trsv(vt, uplo, diag, n, A, lda, x, incx, helper, stream=None):

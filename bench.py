@@ -65,32 +65,76 @@ def parse_args():
     return p.parse_args()
 
 
-def launch_ranks(world, argv, command=None, timeout=None, poll=0.05):
+def _die_with_parent():
+    """preexec_fn of a rank: the kernel sends SIGKILL to this child when the
+    process that started it dies, however that happens (SIGKILL included, which
+    no handler in the parent can catch). Only prctl: no GPU, no exec."""
+    import ctypes
+    PR_SET_PDEATHSIG = 1
+    ctypes.CDLL(None, use_errno=True).prctl(PR_SET_PDEATHSIG, int(signal.SIGKILL), 0, 0, 0)
+
+
+def launch_ranks(world, argv, command=None, timeout=None, poll=0.05, attempts=3):
     """Parent side of `python bench.py --gpus N` without a launcher: starts
     `world` children of `command` (default: this script) with RANK, LOCAL_RANK,
     WORLD_SIZE, MASTER_ADDR = 127.0.0.1 and a free MASTER_PORT, each in its own
     process group. Rank 0's stdout is relayed when every rank has exited with
     0. The first non-zero exit, or the time limit (ACCBLAS_BENCH_LAUNCH_TIMEOUT
     seconds, default 1500), kills every child's process group and is the
-    return value (124 for the time limit). The parent never imports torch or
-    touches the GPU, and no process is replaced by another."""
+    return value (124 for the time limit). SIGTERM / SIGHUP / SIGINT to the
+    parent (a harness `timeout`, a cancelled job) do the same and exit with
+    128 + signal; should the parent be killed outright, every rank gets
+    SIGKILL from the kernel (PR_SET_PDEATHSIG), so no rank outlives it on a
+    GPU. The port is found by bind-and-close, so another process can take it
+    before rank 0 binds it: a job whose rank 0 reports the address in use is
+    started again on a new port (`attempts` times in all). The parent never
+    imports torch or touches the GPU, and no process is replaced by another."""
     if command is None:
         command = [sys.executable, os.path.abspath(__file__)]
     if timeout is None:
         timeout = float(os.environ.get("ACCBLAS_BENCH_LAUNCH_TIMEOUT", "1500"))
+    deadline = time.monotonic() + timeout
+    status = 1
+    for attempt in range(attempts):
+        status, text, errors = _launch_once(world, argv, command, deadline, timeout, poll)
+        in_use = status not in (0, 124) and \
+            ("address already in use" in errors.lower() or "EADDRINUSE" in errors)
+        sys.stderr.write(errors)
+        if not in_use or attempt + 1 == attempts:
+            break
+        print("bench.py: the rendezvous port was taken by another process; "
+              "starting the ranks again on a new one", file=sys.stderr)
+    if status == 0:
+        # stdout carries the result line and nothing else: what libraries of a
+        # rank wrote there besides ("[Gloo] Rank 0 is connected to ...") goes
+        # to stderr
+        lines = text.splitlines()
+        result = [line for line in lines if line.startswith("{")]
+        for line in lines:
+            if not line.startswith("{"):
+                print(line, file=sys.stderr)
+        if result:
+            sys.stdout.write(result[-1] + "\n")
+        else:
+            print("bench.py: rank 0 printed no result line", file=sys.stderr)
+            status = 1
+        sys.stdout.flush()
+    else:
+        # the result line counts only when every rank finished; what rank 0
+        # had printed before a failure goes to stderr
+        sys.stderr.write(text)
+    sys.stderr.flush()
+    return status
+
+
+def _launch_once(world, argv, command, deadline, timeout, poll):
+    """One attempt of `launch_ranks`: (status, rank 0's stdout, rank 0's stderr)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     children = []
     outputs = []
-    for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
-                   WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        out = tempfile.TemporaryFile(mode="w+")
-        outputs.append(out)
-        children.append(subprocess.Popen(list(command) + list(argv), env=env, stdout=out,
-                                         start_new_session=True))
+    rank0_err = tempfile.TemporaryFile(mode="w+")
 
     def kill_all():
         for child in children:
@@ -102,9 +146,39 @@ def launch_ranks(world, argv, command=None, timeout=None, poll=0.05):
         for child in children:
             child.wait()
 
+    def on_signal(signum, _frame):
+        # (handlers run in the main thread between two bytecodes: the list of
+        # children is whatever has been started so far)
+        kill_all()
+        try:
+            rank0_err.seek(0)
+            sys.stderr.write(rank0_err.read())
+        except (OSError, ValueError):
+            pass
+        print(f"bench.py: signal {signum}; the ranks were stopped", file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(128 + signum)
+
+    caught = (signal.SIGTERM, signal.SIGHUP, signal.SIGINT)
+    in_main_thread = threading.current_thread() is threading.main_thread()
+    previous = {}
+    if in_main_thread:
+        # before the first child exists: there is no window in which a signal
+        # ends the parent and leaves a rank behind
+        for signum in caught:
+            previous[signum] = signal.signal(signum, on_signal)
     status = 0
-    deadline = time.monotonic() + timeout
     try:
+        for rank in range(world):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
+                       WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            out = tempfile.TemporaryFile(mode="w+")
+            outputs.append(out)
+            children.append(subprocess.Popen(
+                list(command) + list(argv), env=env, stdout=out,
+                stderr=rank0_err if rank == 0 else None,
+                start_new_session=True, preexec_fn=_die_with_parent))
         while True:
             codes = [child.poll() for child in children]
             failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
@@ -124,33 +198,20 @@ def launch_ranks(world, argv, command=None, timeout=None, poll=0.05):
             time.sleep(poll)
     finally:
         kill_all()
-    # the result line counts only when every rank finished; what rank 0 had
-    # printed before a failure goes to stderr
-    outputs[0].seek(0)
-    text = outputs[0].read()
-    if isinstance(text, bytes):
-        text = text.decode(errors="replace")
-    if status == 0:
-        # stdout carries the result line and nothing else: what libraries of a
-        # rank wrote there besides ("[Gloo] Rank 0 is connected to ...") goes
-        # to stderr
-        lines = text.splitlines()
-        result = [line for line in lines if line.startswith("{")]
-        for line in lines:
-            if not line.startswith("{"):
-                print(line, file=sys.stderr)
-        if result:
-            sys.stdout.write(result[-1] + "\n")
-        else:
-            print("bench.py: rank 0 printed no result line", file=sys.stderr)
-            status = 1
-        sys.stdout.flush()
-    else:
-        sys.stderr.write(text)
-        sys.stderr.flush()
+        for signum, handler in previous.items():
+            signal.signal(signum, handler)
+    texts = []
+    for stream in (outputs[0] if outputs else None, rank0_err):
+        if stream is None:
+            texts.append("")
+            continue
+        stream.seek(0)
+        text = stream.read()
+        texts.append(text.decode(errors="replace") if isinstance(text, bytes) else text)
     for out in outputs:
         out.close()
-    return status
+    rank0_err.close()
+    return status, texts[0], texts[1]
 
 
 def cpu_baseline(oracle, ar, A_rows, lda, x, res_rows, threads, cpu_reps=12):
@@ -216,25 +277,65 @@ class HostStagedCollectives:
         self._dist.destroy_process_group()
 
 
-def event_time_us(accblas, torch, fn, stream, reps=5):
-    """min-of-reps HIP-event time of fn() in microseconds."""
+def event_times_us(accblas, torch, fn, stream, reps=5, setup=None):
+    """(min, mean) HIP-event time of fn() in microseconds over `reps` runs after
+    one warm-up. `setup()` (e.g. restoring an in-place operand) is enqueued
+    BEFORE the start event, so the bracket holds fn()'s launches and nothing
+    else - nothing is subtracted afterwards."""
+    if setup is not None:
+        setup()
     fn()
     torch.cuda.synchronize()
-    best = float("inf")
+    times = []
     for _ in range(reps):
+        if setup is not None:
+            setup()
         a, b = accblas.Event(), accblas.Event()
         a.record(stream)
         fn()
         b.record(stream)
         b.synchronize()
-        best = min(best, a.elapsed_ms(b) * 1e3)
-    return best
+        times.append(a.elapsed_ms(b) * 1e3)
+    return min(times), sum(times) / len(times)
 
 
-def other_configs(accblas, torch, dev, stream, dist, world, rank):
+def event_time_us(accblas, torch, fn, stream, reps=5, setup=None):
+    """min-of-reps HIP-event time of fn() in microseconds."""
+    return event_times_us(accblas, torch, fn, stream, reps, setup)[0]
+
+
+def batch_times_us(accblas, fn, stream, launches, batches=10):
+    """(min, mean) per-launch time over `batches` event-bracketed batches of
+    `launches` back-to-back calls of fn()."""
+    times = []
+    for _ in range(batches):
+        a, b = accblas.Event(), accblas.Event()
+        a.record(stream)
+        for _ in range(launches):
+            fn()
+        b.record(stream)
+        b.synchronize()
+        times.append(a.elapsed_ms(b) * 1e3 / launches)
+    return min(times), sum(times) / len(times)
+
+
+def recomputable(kernel, algorithmic_bytes, us_min, us_mean, protocol):
+    """The fields every entry of `other_configs` carries so that a reader can
+    redo the arithmetic: frac_of_8TBs = algorithmic_bytes / us_min / 8e6."""
+    return {"kernel": kernel, "algorithmic_bytes": algorithmic_bytes,
+            "us_min": us_min, "us_mean": us_mean, "protocol": protocol,
+            "GBs": algorithmic_bytes / us_min / 1e3,
+            "frac_of_8TBs": algorithmic_bytes / us_min / 1e3 / HBM_PEAK_GBS}
+
+
+def other_configs(accblas, torch, dev, stream, dist, world, rank, headline=None):
     """The remaining BASELINE.json configurations, measured outside the timed
-    region of the headline metric (min-of-5 event times). Every rank runs this
-    (the sharded dot needs all of them); rank 0 reports."""
+    region of the headline metric (HIP events around the kernel launches only).
+    Every rank runs this (the sharded dot needs all of them); rank 0 reports.
+    Every entry carries `kernel`, `algorithmic_bytes`, `us_min`, `us_mean` and
+    `protocol` (`recomputable`). `headline` = (A, lda, x, res, st, ar, rows,
+    cols) of the headline problem, still resident: the row block one GPU of
+    eight would own is timed on it at N = 1."""
     F16, F32, F64 = accblas.F16, accblas.F32, accblas.F64
     out = {}
 
@@ -253,16 +354,54 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank):
     accblas.acc_gemv(F64, F64, n, n, 1.0, A, n, x, 1, 1.0, r_acc, 1, stream)
     torch.cuda.synchronize()
     identical = bool(torch.equal(r_plain, r_acc))
-    t_plain = event_time_us(accblas, torch, lambda: accblas.gemv(
-        F64, n, n, 1.0, A, n, x, 1, 1.0, r_plain, 1, stream), stream)
-    t_acc = event_time_us(accblas, torch, lambda: accblas.acc_gemv(
-        F64, F64, n, n, 1.0, A, n, x, 1, 1.0, r_acc, 1, stream), stream)
+    t_plain, t_plain_mean = event_times_us(accblas, torch, lambda: accblas.gemv(
+        F64, n, n, 1.0, A, n, x, 1, 1.0, r_plain, 1, stream), stream, reps=10)
+    t_acc, t_acc_mean = event_times_us(accblas, torch, lambda: accblas.acc_gemv(
+        F64, F64, n, n, 1.0, A, n, x, 1, 1.0, r_acc, 1, stream), stream, reps=10)
     byts = 8.0 * (n * n + 3 * n)
-    out["gemv_16384_fp64_fp64"] = {
-        "plain_us": t_plain, "acc_us": t_acc, "plain_GBs": byts / t_plain / 1e3,
-        "acc_GBs": byts / t_acc / 1e3, "acc_frac_of_8TBs": byts / t_acc / 1e3 / HBM_PEAK_GBS,
-        "plain_equals_accessor_bitwise": identical}
+    out["gemv_16384_fp64_fp64"] = dict(
+        recomputable("accblas::dev::kernel::gemv_vec (Acc<fp64, fp64> through the accessor)",
+                     byts, t_acc, t_acc_mean,
+                     "warm-up, then min / mean of 10 event-timed launches"),
+        plain_us=t_plain, plain_us_mean=t_plain_mean, acc_us=t_acc,
+        plain_GBs=byts / t_plain / 1e3, acc_GBs=byts / t_acc / 1e3,
+        acc_frac_of_8TBs=byts / t_acc / 1e3 / HBM_PEAK_GBS,
+        plain_equals_accessor_bitwise=identical)
     del A, x, r0, r_plain, r_acc
+
+    # -- the shape ONE GPU of an 8-GPU run of the headline problem sees: a row
+    # block of rows/8 rows of the SAME matrix (4096 x 32768 fp32 = 512 MiB, 67 us
+    # of HBM time). Rotating over all 8 row blocks (4 GiB between two uses of a
+    # line) keeps the Infinity Cache out of it.
+    if world == 1 and headline is not None:
+        hA, hlda, hx, hres, hst, har, hrows, hcols = headline
+        share = hrows // 8
+        blocks = hrows // share
+        sbytes = accblas.DTYPE_BYTES[hst]
+        turn_g = [0]
+
+        def block_gemv(rotate=True):
+            k = turn_g[0] % blocks if rotate else 0
+            turn_g[0] += 1
+            lo = k * share
+            accblas.acc_gemv(har, hst, share, hcols, 1.0, hA[lo * hlda:], hlda, hx, 1, 1.0,
+                             hres[lo:], 1, stream)
+
+        t_one, t_one_mean = event_times_us(accblas, torch, block_gemv, stream, reps=3 * blocks)
+        t_same = event_time_us(accblas, torch, lambda: block_gemv(False), stream, reps=10)
+        block_gemv()
+        torch.cuda.synchronize()
+        t_b2b, t_b2b_mean = batch_times_us(accblas, block_gemv, stream, 3 * blocks)
+        byts = sbytes * (share * hcols + 2.0 * share + hcols)
+        out[f"gemv_rowblock_{share}x{hcols}_one_gpu_share_of_8"] = dict(
+            recomputable("accblas::dev::kernel::gemv_vec", byts, t_one, t_one_mean,
+                         f"row blocks k = 0..{blocks - 1} of the headline matrix in turn "
+                         f"(HBM-sourced); us_min / us_mean: {3 * blocks} event-timed single "
+                         "launches"),
+            rows=share, cols=hcols,
+            us_back_to_back=t_b2b, us_back_to_back_mean_of_10_batches=t_b2b_mean,
+            frac_of_8TBs_back_to_back=byts / t_b2b / 1e3 / HBM_PEAK_GBS,
+            us_same_row_block=t_same)
 
     # -- configs[3]: dot n = 2^28, storage fp16, arithmetic fp32, chunked over the
     # ranks, one all-reduce of a single fp32 element
@@ -303,18 +442,7 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank):
     torch.cuda.synchronize()
     # back-to-back launches over the rotating buffers, per-launch average; the
     # minimum over 10 such batches (the reference's min-of-10 protocol)
-    t_kernel = float("inf")
-    t_kernel_mean = 0.0
-    for _ in range(10):
-        a, b = accblas.Event(), accblas.Event()
-        a.record(stream)
-        for _ in range(reps):
-            local_dot(lo, hi)
-        b.record(stream)
-        b.synchronize()
-        t_batch = a.elapsed_ms(b) * 1e3 / reps
-        t_kernel = min(t_kernel, t_batch)
-        t_kernel_mean += t_batch / 10
+    t_kernel, t_kernel_mean = batch_times_us(accblas, lambda: local_dot(lo, hi), stream, reps)
     multi_gpu.sharded_dot(local_dot, n_total, dist=dist, align=align)  # warm-up incl. RCCL
     torch.cuda.synchronize()
     if dist is not None:
@@ -333,6 +461,10 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank):
         t_kernel, t_e2e, t_resident = float(t[0]), float(t[1]), float(t[2])
     want = float(ref.item())
     out["dot_2p28_fp16_fp32"] = {
+        "kernel": "accblas::dev::kernel::dot (Acc<fp32, fp16>, deterministic hand-off)",
+        "algorithmic_bytes": 4.0 * count, "us_min": t_kernel, "us_mean": t_kernel_mean,
+        "protocol": f"min / mean over 10 batches of {reps} back-to-back launches sweeping "
+                    f"{copies} buffer sets in turn (per-launch average)",
         "elements_per_gpu": count, "kernel_us": t_kernel,
         "kernel_GBs_per_gpu": 4.0 * count / t_kernel / 1e3,
         "kernel_frac_of_8TBs": 4.0 * count / t_kernel / 1e3 / HBM_PEAK_GBS,
@@ -372,16 +504,10 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank):
 
         t_same = event_time_us(accblas, torch, lambda: chunk_dot(False), stream, reps=10)
         t_single = event_time_us(accblas, torch, chunk_dot, stream, reps=4 * pairs)
-        t_hbm = float("inf")
-        for _ in range(10):
-            a, b = accblas.Event(), accblas.Event()
-            a.record(stream)
-            for _ in range(4 * pairs):
-                chunk_dot()
-            b.record(stream)
-            b.synchronize()
-            t_hbm = min(t_hbm, a.elapsed_ms(b) * 1e3 / (4 * pairs))
+        t_hbm, t_hbm_mean = batch_times_us(accblas, chunk_dot, stream, 4 * pairs)
         out["dot_chunk_2p25_fp16_fp32_one_gpu_share_of_8"] = {
+            "kernel": "accblas::dev::kernel::dot (Acc<fp32, fp16>, deterministic hand-off)",
+            "algorithmic_bytes": 4.0 * chunk, "us_min": t_hbm, "us_mean": t_hbm_mean,
             "elements": chunk, "bytes": 4 * chunk,
             "hbm_us_back_to_back": t_hbm,
             "hbm_GBs": 4.0 * chunk / t_hbm / 1e3,
@@ -396,39 +522,44 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank):
         del xc, yc
 
     # -- configs[4]: TRSV n = 65536, lower, unit diagonal, storage fp32,
-    # arithmetic fp64; does not shard (replicas only), so rank 0 only
+    # arithmetic fp64, and the reference CLI's default (upper / unit, n = 24000,
+    # cuda/trsv_benchmark.cu:26-30); does not shard (replicas only): rank 0 only
     if rank == 0:
-        n = 65536
-        L = uniform(n * n, torch.float32, scale=1.0 / n ** 0.5, seed=31)
-        b = uniform(n, torch.float32, seed=32)
-        xs = b.clone()
-        helper = torch.zeros(2, dtype=torch.int32, device=dev)
+        for n, uplo, uplo_name in ((65536, accblas.LOWER, "lower"),
+                                   (24000, accblas.UPPER, "upper")):
+            L = uniform(n * n, torch.float32, scale=1.0 / n ** 0.5, seed=31)
+            b = uniform(n, torch.float32, seed=32)
+            xs = b.clone()
+            helper = torch.zeros(2, dtype=torch.int32, device=dev)
 
-        def solve():
+            def solve():
+                accblas.acc_trsv(F64, F32, uplo, accblas.UNIT, n, L, n, xs, 1, helper, stream)
+            # the reference's protocol (warm-up, then the minimum of 10 runs,
+            # cuda/utils.cuh:236-262) with x restored BEFORE the start event:
+            # the bracket holds the solve's one launch and nothing else
+            t_trsv, t_trsv_mean = event_times_us(accblas, torch, solve, stream, reps=10,
+                                                 setup=lambda: xs.copy_(b))
             xs.copy_(b)
-            accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, L, n, xs, 1, helper,
-                             stream)
-        # (the reference's protocol: warm-up, then the minimum of 10 runs,
-        # cuda/utils.cuh:236-262)
-        t_solve = event_time_us(accblas, torch, solve, stream, reps=10)
-        t_copy = event_time_us(accblas, torch, lambda: xs.copy_(b), stream, reps=10)
-        solve()
-        torch.cuda.synchronize()
-        # residual of 256 sampled rows in fp64: (L x)_i + x_i - b_i
-        rows = torch.randint(0, n, (256,), device=dev)
-        Lr = L.view(n, n)[rows].double()
-        cols = torch.arange(n, device=dev)
-        Lr = torch.where(cols[None, :] < rows[:, None], Lr, torch.zeros_like(Lr))
-        resid = Lr @ xs.double() + xs.double()[rows] - b.double()[rows]
-        byts = 4.0 * (n * (n - 1) / 2 + 2 * n)
-        t_trsv = t_solve - t_copy
-        out["trsv_65536_lower_unit_fp32_fp64"] = {
-            "us": t_trsv, "GBs": byts / t_trsv / 1e3,
-            "frac_of_8TBs": byts / t_trsv / 1e3 / HBM_PEAK_GBS,
-            "us_per_64row_hop": t_trsv / (n / 64),
-            "sampled_residual_rel": float(resid.abs().sum() / b.double()[rows].abs().sum()),
-            "helper_word": int(helper[0].item()) & 0xffffffff}
-        del L
+            solve()
+            torch.cuda.synchronize()
+            # residual of 256 sampled rows in fp64: (T x)_i + x_i - b_i
+            rows = torch.randint(0, n, (256,), device=dev)
+            Lr = L.view(n, n)[rows].double()
+            cols = torch.arange(n, device=dev)
+            keep = cols[None, :] < rows[:, None] if uplo == accblas.LOWER \
+                else cols[None, :] > rows[:, None]
+            Lr = torch.where(keep, Lr, torch.zeros_like(Lr))
+            resid = Lr @ xs.double() + xs.double()[rows] - b.double()[rows]
+            byts = 4.0 * (n * (n - 1) / 2 + 2 * n)
+            out[f"trsv_{n}_{uplo_name}_unit_fp32_fp64"] = dict(
+                recomputable("accblas::dev::kernel::trsv_wide", byts, t_trsv, t_trsv_mean,
+                             "x restored by a device copy enqueued before the start event; "
+                             "warm-up, then min / mean of 10 event-timed solves (one launch "
+                             "each)"),
+                us=t_trsv, us_per_128row_hop=t_trsv / (n / 128),
+                sampled_residual_rel=float(resid.abs().sum() / b.double()[rows].abs().sum()),
+                helper_word=int(helper[0].item()) & 0xffffffff)
+            del L, Lr
     torch.cuda.empty_cache()
     return out
 
@@ -631,10 +762,11 @@ def main():
     sample_rows = min(rows, 16384)
     want_cpu = world == 1 and not args.no_cpu_baseline
     A_sample = A_st[: sample_rows * lda].cpu().numpy() if want_cpu else None
-    del A_st  # (kept in the allocator, see above: the other configs are timed next)
     extras = None
     if not args.no_other_configs and n == 32768:
-        extras = other_configs(accblas, torch, dev, stream, dist, world, rank)
+        extras = other_configs(accblas, torch, dev, stream, dist, world, rank,
+                               headline=(A_st, lda, x_st, res_st, st, ar, rows, cols))
+    del A_st  # (stays in torch's allocator, see above)
 
     if rank != 0:
         if dist is not None:

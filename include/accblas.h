@@ -193,6 +193,17 @@ int accblas_acc_dot(accblas_handle *handle, accblas_dtype ar, accblas_dtype st,
                     int64_t incx, const void *y, int64_t incy, void *res,
                     void *stream);
 
+/* Did a deterministic dot on `handle` give up? In the default mode the last
+ * workgroup of the grid collects the other workgroups' partial sums and waits
+ * for them (bounded: seconds). They need nothing from it, so the wait ends as
+ * soon as they have run - but if another stream's kernel keeps them off the
+ * CUs for that long, the collector writes NaN to *res instead of a partial
+ * result, and this call says so: it synchronises `stream`, sets *expired to 1
+ * if any dot on this handle gave up since the last call (and clears the
+ * mark), else to 0. No reference counterpart (its atomics cannot stall,
+ * cuda/dot_kernels.cuh:158-160); ACCBLAS_DOT_ATOMIC mode never waits. */
+int accblas_dot_status(accblas_handle *handle, void *stream, int *expired);
+
 /* ---- TRSV: x <- T^{-1} x in place ----------------------------------------
  * T = upper/lower triangle of the row-major n x n matrix A (row stride lda),
  * unit or non-unit diagonal. `helper` = 2 device uint32 words owned by the

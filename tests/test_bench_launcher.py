@@ -113,3 +113,99 @@ def test_bench_without_a_launcher_fails_loudly_without_gpus():
         assert run.returncode != 0
         assert run.stdout == ""
         assert "exited with" in run.stderr
+
+
+def _parent_script(tmp_path, child_body, world=2):
+    """A parent process running bench.launch_ranks over dummy ranks that write
+    their pids and then wait for ever."""
+    child = tmp_path / "rank.py"
+    child.write_text(textwrap.dedent(child_body))
+    parent = tmp_path / "parent.py"
+    parent.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, r"{REPO}")
+        import bench
+        sys.exit(bench.launch_ranks({world}, [], command=[sys.executable, r"{child}"],
+                                    timeout=300))
+    """))
+    return [sys.executable, str(parent)]
+
+
+_WAITING_RANK = """
+    import os, time
+    open(r"{dir}/pid" + os.environ["RANK"], "w").write(str(os.getpid()))
+    time.sleep(600)
+"""
+
+
+def _wait_for(paths, seconds=30):
+    end = time.monotonic() + seconds
+    while time.monotonic() < end:
+        if all(p.exists() and p.read_text() for p in paths):
+            return
+        time.sleep(0.05)
+    raise AssertionError("the dummy ranks did not start")
+
+
+def _gone(pids, seconds=15):
+    end = time.monotonic() + seconds
+    while time.monotonic() < end:
+        if not any(_alive(pid) for pid in pids):
+            return True
+        time.sleep(0.05)
+    return False
+
+
+def test_sigterm_to_the_parent_takes_every_rank_with_it(tmp_path):
+    """A harness `timeout` or a cancelled job signals the parent: the ranks
+    (each in its own session) must not be left running on the GPUs."""
+    import signal
+    for signum in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+        for old in tmp_path.glob("pid*"):
+            old.unlink()
+        parent = subprocess.Popen(_parent_script(tmp_path, _WAITING_RANK.format(dir=tmp_path)),
+                                  stderr=subprocess.PIPE, text=True)
+        pid_files = [tmp_path / "pid0", tmp_path / "pid1"]
+        _wait_for(pid_files)
+        pids = [int(p.read_text()) for p in pid_files]
+        assert all(_alive(pid) for pid in pids)
+        parent.send_signal(signum)
+        _, err = parent.communicate(timeout=30)
+        assert parent.returncode == 128 + signum, (parent.returncode, err)
+        assert "the ranks were stopped" in err
+        assert _gone(pids), f"ranks survived signal {signum} to the parent"
+
+
+def test_a_parent_killed_outright_takes_every_rank_with_it(tmp_path):
+    """SIGKILL cannot be handled: the ranks asked the kernel for SIGKILL on the
+    death of their parent (PR_SET_PDEATHSIG)."""
+    import signal
+    parent = subprocess.Popen(_parent_script(tmp_path, _WAITING_RANK.format(dir=tmp_path)))
+    pid_files = [tmp_path / "pid0", tmp_path / "pid1"]
+    _wait_for(pid_files)
+    pids = [int(p.read_text()) for p in pid_files]
+    parent.send_signal(signal.SIGKILL)
+    parent.wait(timeout=30)
+    assert _gone(pids), "ranks survived the death of their parent"
+
+
+def test_a_taken_rendezvous_port_starts_the_ranks_again(tmp_path, capfd):
+    """bind-and-close can lose the port to another process before rank 0 binds
+    it: rank 0 then reports the address in use and the job is started again."""
+    marker = tmp_path / "attempt"
+    cmd = _script(tmp_path, f"""
+        import os, sys
+        marker = r"{marker}"
+        if os.environ["RANK"] == "0" and not os.path.exists(marker):
+            open(marker, "w").write(os.environ["MASTER_PORT"])
+            print("RuntimeError: The server socket has failed to listen on any local "
+                  "network address. port: 1234, useIpv6: false, code: -98, name: "
+                  "EADDRINUSE, message: address already in use", file=sys.stderr)
+            sys.exit(1)
+        print('{{"port": %s}}' % os.environ["MASTER_PORT"])
+    """)
+    status = bench.launch_ranks(2, [], command=cmd, timeout=60)
+    captured = capfd.readouterr()
+    assert status == 0
+    assert captured.out.startswith('{"port": ')
+    assert "starting the ranks again" in captured.err

@@ -764,6 +764,22 @@ def test_trsv_repairs_a_header_left_by_a_dead_solve_or_overwritten(gpu, trsv_ker
     # (4) all ones
     workspace[:4096] = 0xFF
     assert torch.equal(solve(), clean)
+    # (5) all ones over the header of a workspace whose hand-off words carry the
+    # tag the repairer will pick next (epoch 0xffffffff + 1 wraps to the first
+    # epoch, 2) with wrong values: an epoch word that was written over proves
+    # nothing, so the repairer clears the words
+    workspace[:4096] = 0xFF
+    words[:] = (2 << 32) | 0x3F800000
+    assert torch.equal(solve(), clean)
+    # (6) the epoch moved BACK by a scribbler while the word of a dead launch is
+    # in place, words of the epoch that comes next present
+    epoch = int(header[3].item())
+    header[0] = 7
+    header[1] = 0x2468
+    header[3] = epoch - 1
+    words[:] = (epoch << 32) | 0x40000000
+    assert torch.equal(solve(), clean)
+    assert torch.equal(solve(), clean)
 
 
 def test_dot_ignores_whatever_is_in_its_scratch(gpu):
@@ -798,6 +814,36 @@ def test_dot_ignores_whatever_is_in_its_scratch(gpu):
                 accblas.acc_dot(h, F64, F32, F64, n, x, 1, y, 1, res)
                 torch.cuda.synchronize()
                 assert res.item() == clean, fill
+                assert not accblas.dot_status(h)
+    finally:
+        h.close()
+
+
+def test_dot_status_reports_a_collector_that_gave_up_once(gpu):
+    """`accblas_dot_status`: the collector of a deterministic dot leaves a sticky
+    word in the handle when its bounded wait expires (and NaN in *res); the call
+    reports it once and clears it. Healthy dots never set it. The word sits 32
+    bytes behind the handle's scalar slot; the test plants it there, because a
+    healthy device cannot be made to starve a grid for seconds."""
+    torch, accblas = gpu
+    import ctypes
+    lib = accblas.load()
+    h = accblas.Handle()
+    try:
+        n = 100_000
+        x = to_dev(torch, make_inputs(73, n, F32))
+        res = torch.zeros(1, dtype=torch.float32, device="cuda")
+        accblas.acc_dot(h, F32, F32, F32, n, x, 1, x, 1, res)
+        assert not accblas.dot_status(h)
+        scratch = ctypes.c_void_p()
+        assert lib.accblas_handle_device_scratch(h.raw, ctypes.byref(scratch)) == 0
+        word = np.array([0xdeadbeef], dtype=np.uint32)
+        assert lib.accblas_memcpy_h2d(ctypes.c_void_p(scratch.value + 32),
+                                      word.ctypes.data_as(ctypes.c_void_p), 4) == 0
+        assert accblas.dot_status(h)
+        assert not accblas.dot_status(h)
+        accblas.acc_dot(h, F32, F32, F32, n, x, 1, x, 1, res)
+        assert not accblas.dot_status(h) and np.isfinite(res.item())
     finally:
         h.close()
 
