@@ -71,23 +71,18 @@ int trsv_relay_option_value();
 
 /** Where the 128-row kernel is the faster one. 2- and 4-byte storage: from
  *  n = 4096 on (profiles/r02_trsv_ab_final.txt: 4-7 % faster at 4096, 17-20 % at
- *  8192, 27-50 % at 24000-65536). 8-byte storage (two half-width steps in
- *  flight are all the registers allow), re-measured at the end of round 3 with
- *  the lane-move reductions in the 64-row kernel and the prefetching workgroups
- *  in the 128-row one (profiles/r03_trsv_prefetch.txt, us, 64-row | 128-row |
- *  128-row with prefetchers): 4096 98 | 104 | 89, 8192 213 | 221 | 164, 16384
- *  453 | 440 | 389, 18432 437 | 493 | 469 (the 64-row kernel's relay sets in
- *  at 17000), 24000 645 | 677 | 685, 32768 844 | 973 | 979, 40000 1377 | 1232,
- *  65536 2746 | 2637: the 128-row kernel from 4096 up to the relay's threshold
- *  and again where there are more row blocks than CUs. */
+ *  8192, 27-50 % at 24000-65536). 8-byte storage: nowhere any more. Until round
+ *  3 the 128-row kernel (two half-width steps in flight are all its registers
+ *  allow) won below 17000 and beyond 32768; since round 4 the 64-row kernel's
+ *  relay variant keeps its ring of panels in flight and its workgroups draw
+ *  tickets until none is left (see `kernel::trsv`), and it is the faster one at
+ *  every size measured (profiles/r04_trsv_relay_ring.txt, us, 64-row relay |
+ *  128-row with prefetchers or split blocks): 4096 82 | 89, 8192 160 | 168,
+ *  12288 244 | 267, 16384 329 | 392, 24000 523 | 677, 32768 796 | 978, 40000
+ *  1139 | 1270, 49152 1684 | 1726, 57344 2074 | 2082, 61440 2359 | 2333, 65536
+ *  2785 | 2705 (within 3 % of each other from 52000 on). */
 #ifndef ACCBLAS_TRSV_WIDE_MIN_N
 #define ACCBLAS_TRSV_WIDE_MIN_N 4096
-#endif
-#ifndef ACCBLAS_TRSV_WIDE_8BYTE_GAP_FROM
-#define ACCBLAS_TRSV_WIDE_8BYTE_GAP_FROM 17000
-#endif
-#ifndef ACCBLAS_TRSV_WIDE_8BYTE_GAP_TO
-#define ACCBLAS_TRSV_WIDE_8BYTE_GAP_TO 32768
 #endif
 
 
@@ -130,9 +125,7 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
     const bool use_wide =
         wide != 0 && dev::trsv_wide_applicable(upper, mtx) &&
         (wide == 2 ||
-         (n >= ACCBLAS_TRSV_WIDE_MIN_N &&
-          (sizeof(st_type) < 8 || n < ACCBLAS_TRSV_WIDE_8BYTE_GAP_FROM ||
-           n > ACCBLAS_TRSV_WIDE_8BYTE_GAP_TO)));
+         (n >= ACCBLAS_TRSV_WIDE_MIN_N && sizeof(st_type) < 8));
     if (use_wide) {
         return check_hip(
             dev::launch_trsv_wide<ar_type>(upper, unit_diag, mtx, x, helper,
@@ -144,7 +137,8 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
     }
     return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x, helper,
                                                session, as_stream(stream),
-                                               trsv_relay_option_value()),
+                                               trsv_relay_option_value(),
+                                               trsv_num_cus()),
                      "trsv launch");
 }
 

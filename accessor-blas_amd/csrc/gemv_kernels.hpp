@@ -512,6 +512,26 @@ static_assert(gemv_short_config::wpr == gemv_short_tall_config::wpr &&
                   gemv_short_config::unroll == gemv_short_tall_config::unroll,
               "the two short-row shapes must sum a row in the same order");
 
+/** Matrices that fit the Infinity Cache (256 MiB; with the way it is filled a
+ *  cyclic re-read still hits up to ~320 MB) are loaded with the DEFAULT cache
+ *  policy instead of the non-temporal hint: an iterative solver - what the
+ *  accessor is for - multiplies with the same matrix again and again, and so
+ *  does the reference's benchmark (10 timed runs per size). Measured against the
+ *  non-temporal production shape (profiles/r04_tune_gemv_mall.txt, lda = 24500,
+ *  us): Acc<fp64,fp32> n = 5500 24.0 -> 21.2, 6500 32.3 -> 28.0, 7000 35.0 ->
+ *  30.8, 8000 42.4 -> 38.7, 8500 50.9 -> 46.0, 9000 54.8 -> 52.6, but 10000
+ *  (400 MB) 63.4 -> 67.8; fp64 4000 24.8 -> 21.6, 5000 34.7 -> 30.9, 6000 46.8
+ *  -> 44.0, equal from 6500 (338 MB) on. The cached shape has two rows per
+ *  group instead of four (finer balance between the CUs while the data comes
+ *  from the cache) and the SAME waves per row and unroll as the production
+ *  shape: a row is summed in the same order, so a row block still has the bits
+ *  of the same rows inside a larger product whichever of the two it runs. */
+using gemv_cached_config = gemv_config<8, 4, 2, 2, false>;
+constexpr index_type gemv_cached_max_bytes = index_type{320} * 1000 * 1000;
+static_assert(gemv_cached_config::wpr == gemv_default_config::wpr &&
+                  gemv_cached_config::unroll == gemv_default_config::unroll,
+              "the cached shape must sum a row in the production shape's order");
+
 /** When the time-skewed sweep is used (option "gemv_skew" of the C ABI). */
 enum class gemv_skew_mode {
     never = 0,
@@ -633,6 +653,17 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
                                dim3(shape::waves * wave_size), 0, stream>>>(
                                 alpha, mtx, x, beta, res);
                     }
+                } else if (std::is_same<Config, gemv_default_config>::value &&
+                           rows * cols *
+                                   static_cast<index_type>(sizeof(st_type)) <=
+                               gemv_cached_max_bytes) {
+                    // fits the Infinity Cache: default cache policy
+                    using shape = gemv_cached_config;
+                    kernel::gemv_vec<shape, vec16, true, false, false>
+                        <<<dim3(static_cast<unsigned>(
+                               ceildiv(rows, shape::rows_per_block))),
+                           dim3(shape::waves * wave_size), 0, stream>>>(
+                            alpha, mtx, x, beta, res);
                 } else {
                     kernel::gemv_vec<Config, vec16, true, false, false>
                         <<<grid, block, 0, stream>>>(alpha, mtx, x, beta, res);

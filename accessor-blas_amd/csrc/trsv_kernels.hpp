@@ -88,18 +88,20 @@ constexpr int trsv_granule_words()
 // block records 100 MHz wall-clock stamps of its phases into a buffer that no
 // other code reads. The library is never built with it.
 #ifdef ACCBLAS_TRSV_DIAG
+// (the stamps live in wave 0's registers and are written once, at the end of
+// the block: a store - or the load of this pointer - inside the sweep would
+// sit in the memory queues the stamps are meant to observe)
 __device__ unsigned long long *trsv_diag_buffer;
-#define ACCBLAS_TRSV_STAMP(_block, _slot)                                  \
-    do {                                                                   \
-        if (lane_id() == 0 && trsv_diag_buffer != nullptr) {               \
-            trsv_diag_buffer[(_block)*16 + (_slot)] = wall_clock64();       \
-        }                                                                  \
-    } while (false)
-#define ACCBLAS_TRSV_CYCLES(_block, _slot)                                 \
-    do {                                                                   \
-        if (lane_id() == 0 && trsv_diag_buffer != nullptr) {               \
-            trsv_diag_buffer[(_block)*16 + (_slot)] = clock64();            \
-        }                                                                  \
+#define ACCBLAS_TRSV_STAMP(_block, _slot) diag_stamp[_slot] = wall_clock64()
+#define ACCBLAS_TRSV_CYCLES(_block, _slot) diag_stamp[_slot] = clock64()
+// first time the far sweep of wave 0 had to wait for a panel's x: when, and
+// which panel (slots 13, 14)
+#define ACCBLAS_TRSV_FIRST_WAIT(_panel)                                     \
+    do {                                                                    \
+        if (diag_stamp[13] == 0) {                                          \
+            diag_stamp[13] = wall_clock64();                                \
+            diag_stamp[14] = static_cast<unsigned long long>(_panel);       \
+        }                                                                   \
     } while (false)
 #else
 #define ACCBLAS_TRSV_STAMP(_block, _slot) \
@@ -107,6 +109,9 @@ __device__ unsigned long long *trsv_diag_buffer;
     } while (false)
 #define ACCBLAS_TRSV_CYCLES(_block, _slot) \
     do {                                   \
+    } while (false)
+#define ACCBLAS_TRSV_FIRST_WAIT(_panel) \
+    do {                                \
     } while (false)
 #endif
 
@@ -208,6 +213,8 @@ namespace detail {
 // wrong result that the caller can detect (helper[0] != ~0u) instead of a hung
 // GPU.
 constexpr unsigned int trsv_spin_limit = 1u << 21;
+// bound of a wait that polls LDS only (one look per ~100 cycles: seconds)
+constexpr unsigned int trsv_lds_spin_limit = 1u << 25;
 constexpr std::uint32_t trsv_error_word = 0xdeadbeefu;
 
 /** Returns true when the caller must stop waiting. */
@@ -707,13 +714,21 @@ __device__ __forceinline__ void invert_tile64(ar_type *tile, ar_type *scratch_a,
  * ArType, x stored as StType and re-read by later blocks as stored.
  */
 template <int Waves, bool Upper, bool UnitDiag, int Vec, bool Relay,
-          typename ArType, typename MtxView, typename XView>
+          typename ArType, bool Persistent = false, typename MtxView,
+          typename XView>
 __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     MtxView mtx, XView x, std::uint32_t *helper, trsv_session session)
 {
     using ar_type = decltype(mtx(0, 0) * x(0, 0));
     static_assert(std::is_same<ArType, ar_type>::value,
                   "accessor arithmetic must yield ArType");
+#ifdef ACCBLAS_TRSV_ENTRY_NOPS
+    // (tools/tune_trsv_align.hip only: shifts the kernel's code by 4 bytes per
+    // s_nop to see what instruction alignment does to the solve)
+#define ACCBLAS_TRSV_STR2(_x) #_x
+#define ACCBLAS_TRSV_STR(_x) ACCBLAS_TRSV_STR2(_x)
+    asm volatile(".rept " ACCBLAS_TRSV_STR(ACCBLAS_TRSV_ENTRY_NOPS) "\n s_nop 0\n .endr");
+#endif
     using mtx_traits = view_traits<MtxView>;
     using x_traits = view_traits<XView>;
     using st_type = std::remove_cv_t<typename x_traits::storage_type>;
@@ -734,18 +749,18 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     __shared__ ar_type partial_a[Waves * B];
     __shared__ ar_type partial_b[Waves * B];
     __shared__ ar_type x_prev_lds[B];
+    __shared__ ar_type own_lds[B];  // this block's right-hand side
     __shared__ std::int32_t shared_block;
     constexpr int XK = 16;  // panels of x in the LDS ring of the far sweep
     __shared__ ar_type x_ring[XK][B];
-    __shared__ volatile std::int32_t x_ring_tag[XK];       // panel index + 1
-    __shared__ volatile std::int32_t sweep_progress[Waves];  // panels consumed
+    __shared__ std::int32_t x_ring_tag[XK];       // panel index + 1
+    __shared__ std::int32_t sweep_progress[Waves];  // panels consumed
+    // relay variant: set when the loader's bounded wait gave up or a worker
+    // waited "for ever" on the ring: the workers' waits look at LDS only
+    __shared__ std::int32_t relay_abort;
 
-    const int lane = lane_id();
-    const int wave = wave_id();
-    // waves 0 .. Waves-1 work on the block's rows; wave `Waves` is the loader:
-    // it feeds the solutions of earlier blocks into LDS for the far sweep
-    // (see there) and otherwise only takes part in the barriers
-    const bool worker = !Relay || wave < Waves;
+    const int lane_of_thread = lane_id();
+    const int wave_of_thread = wave_id();
     // `n` = the size the blocks are laid out for (vector path of an upper
     // solve: `pad` virtual unknowns in front, see `trsv_virtual_pad`); logical
     // index l exists if pad <= l < n
@@ -762,11 +777,87 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
 
     granule_word *const granules = session.granules;
     __shared__ std::uint32_t shared_epoch;
+    __shared__ bool is_last;
+    // Row blocks of the solve, and the events the LAST of which re-arms the
+    // workspace: every row block done and every workgroup's final draw.
+    const unsigned int num_blocks =
+        static_cast<unsigned int>(ceildiv(n, index_type{B}));
+    // (a launch with a workgroup for every row block - small systems - has
+    // nobody draw a second ticket: the kernel would only end two atomic round
+    // trips later)
+    // (Persistent = false: the grid has a workgroup per row block; its code
+    // has no loop around the row block, whose invariants the compiler would
+    // compute up front and keep in registers, see below)
+    constexpr bool persistent = Persistent;
+    const unsigned int last_event =
+        persistent ? num_blocks + gridDim.x - 1 : num_blocks - 1;
+    constexpr std::int32_t no_block_left = 0x3ffffffe;
+    constexpr std::int32_t no_ticket = 0x3fffffff;
+    // The last thing a workgroup does with the workspace (every thread calls
+    // it): counts the event, and the last one of the solve resets the
+    // counters for its successor.
+    const auto count_event = [&](std::uint32_t epoch_now) {
+        if (threadIdx.x == 0) {
+            const unsigned int done = __hip_atomic_fetch_add(
+                &session.state->finished, 1u, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+            is_last = done == last_event;
+        }
+        __syncthreads();
+        if (is_last) {
+            std::uint32_t next_epoch = epoch_now + 1;
+            if (next_epoch == 0) {
+                // 2^32 solves on this workspace: stale tags could repeat
+                for (index_type i = threadIdx.x; i < session.capacity_words;
+                     i += blockDim.x) {
+                    __hip_atomic_store(granules + i, granule_word{0},
+                                       __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                next_epoch = trsv_first_epoch;
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                detail::rearm_state(session.state, next_epoch);
+            }
+        }
+    };
+    // A workgroup solves row blocks until the tickets run out: the launch has
+    // at most one workgroup per CU (`launch_trsv`), and a CU whose block is
+    // done draws the next ticket at once. With one workgroup per ROW BLOCK the
+    // blocks beyond the CU count wait for the hardware dispatcher, which hands
+    // workgroup k to XCD k mod 8 whatever is free elsewhere: the row blocks
+    // with the MOST far columns then start when the last XCD's first blocks
+    // are through (n = 22100, 8-byte storage: ticket 336 of 346 drawn 207-310
+    // us into a 480-590 us solve, with 10 MB to stream before the chain
+    // arrives, while the CUs of seven XCDs idle; whether they made it decided
+    // between two run-time modes 20 % apart, profiles/r04_trsv_plain_vs_acc.txt).
+    for (;;) {
+    // (lane and wave index are made opaque once per row block: everything
+    // the body computes from them - a few hundred LDS and matrix addresses -
+    // is invariant in this loop, and the compiler would otherwise compute all
+    // of it in front of the loop and keep it in registers: 168 registers and
+    // 200-590 bytes of scratch instead of 78-129 registers)
+    int lane_now = lane_of_thread;
+    int wave_now = wave_of_thread;
+    asm volatile("" : "+v"(lane_now), "+v"(wave_now));
+    const int lane = lane_now;
+    const int wave = wave_now;
+#ifdef ACCBLAS_TRSV_DIAG
+    unsigned long long diag_stamp[16] = {};
+#endif
+    // waves 0 .. Waves-1 work on the block's rows; wave `Waves` is the loader:
+    // it feeds the solutions of earlier blocks into LDS for the far sweep
+    // (see there) and otherwise only takes part in the barriers
+    const bool worker = !Relay || wave < Waves;
     if (threadIdx.x < XK) {
         x_ring_tag[threadIdx.x] = 0;
     }
     if (threadIdx.x < Waves) {
         sweep_progress[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) {
+        relay_abort = 0;
     }
     if (threadIdx.x == 0) {
         // the previous solve on this workspace finished before this kernel
@@ -776,10 +867,12 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
                                 session.granules, session.capacity_words);
         const unsigned int ticket = drawn.ticket;
         shared_epoch = drawn.epoch;
-        // (a ticket that could not be had - ~0u - is out of range: the
-        // workgroup leaves, helper[0] says why)
-        shared_block = ticket < gridDim.x ? static_cast<std::int32_t>(ticket)
-                                          : std::int32_t{0x3fffffff};
+        // (a ticket that could not be had - ~0u -: the workgroup leaves
+        // without a word, helper[0] says why; a ticket beyond the last row
+        // block: nothing left to do)
+        shared_block = ticket < num_blocks
+                           ? static_cast<std::int32_t>(ticket)
+                           : (ticket == ~0u ? no_ticket : no_block_left);
         if (ticket == 0) {
             // `trsv_init` (cuda/trsv_kernels.cuh:38-42) folded into the first
             // block: helper[0] stays ~0 unless a bounded spin expires (nobody
@@ -787,16 +880,20 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
             // the reference's block counter after the solve
             __hip_atomic_store(helper, ~std::uint32_t{0}, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-            helper[1] = gridDim.x;
+            helper[1] = num_blocks;
         }
     }
     __syncthreads();
     const index_type block = shared_block;
     const std::uint32_t epoch = shared_epoch;
-    const index_type base = block * B;
-    if (base >= n) {
-        return;  // cannot happen: the grid has exactly ceil(n / B) blocks
+    if (block == no_block_left) {
+        count_event(epoch);
+        return;
     }
+    if (block == no_ticket) {
+        return;
+    }
+    const index_type base = block * B;
     if (wave == 0) {
         ACCBLAS_TRSV_STAMP(block, 0);  // ticket drawn
     }
@@ -813,8 +910,14 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     const index_type own_row = base + lane;
     const bool own_valid = exists(own_row);
     st_type *own_addr = x_data + phys(inside(own_row)) * x_inc;
-    const st_type own_raw = *own_addr;  // (clamped address: unconditional)
-    const ar_type own_rhs = own_valid ? static_cast<ar_type>(own_raw) : ar_type{};
+    // (kept in LDS, not in a register of every wave, until the far sweep is
+    // over: the far sweep needs the registers)
+    // (the load goes out ahead of the tile's, the value is parked in LDS
+    // behind them: one memory latency for all)
+    st_type own_raw{};
+    if (wave == 0) {
+        own_raw = *own_addr;  // (clamped address: unconditional)
+    }
 
     // ---- diagonal tile and last panel -> LDS (a wave reads one row) -------
     // Every load of the wave's rows is issued before the first use, so the
@@ -858,6 +961,9 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
                         : ar_type{};
             }
         }
+    }
+    if (wave == 0) {
+        own_lds[lane] = own_valid ? static_cast<ar_type>(own_raw) : ar_type{};
     }
     __syncthreads();
 
@@ -1044,13 +1150,32 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
                 xv[e] = static_cast<ar_type>(io::decode(s.xraw[e]));
             }
         } else {
-            while (x_ring_tag[slot] != wanted &&
-                   !detail::spin_expired(spins, helper)) {
+            // The wait looks at LDS and nothing else. A worker's vector-memory
+            // queue must hold its matrix loads ONLY: with `spin_expired`'s
+            // load of helper[0] in this loop the compiler cannot count what
+            // is outstanding and puts `s_waitcnt vmcnt(0)` behind every
+            // panel's FMAs - the wave then waits for the panel it has just
+            // requested, the ring is one panel deep in time whatever its
+            // depth on paper, and a row block that starts late (more blocks
+            // than CUs) streams 32 KB per memory latency, too slow to be
+            // ready when the chain reaches it (profiles/r04_trsv_relay_ring.txt).
+            // The loader (which has no matrix loads) keeps the bounded wait
+            // on memory and raises `relay_abort` when it gives up.
+            unsigned int lds_spins = 0;
+            while (lds_flag_load(&x_ring_tag[slot]) != wanted) {
+                if (lds_flag_load(&relay_abort) != 0 ||
+                    ++lds_spins >= detail::trsv_lds_spin_limit) {
+                    lds_flag_store(&relay_abort, 1);
+                    break;
+                }
+                if (wave == 0) {
+                    ACCBLAS_TRSV_FIRST_WAIT(cb);
+                }
                 // eight waves spinning on LDS at full rate would take issue
                 // slots from the loader on the same SIMDs
                 __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            lds_acquire();
 #pragma unroll
             for (int e = 0; e < Vec; ++e) {
                 xv[e] = x_ring[slot][col_group * Vec + e];
@@ -1085,10 +1210,18 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
         // progress store, after which the loader may overwrite the slot; LDS
         // serves a wave's operations in order
         if (Relay) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            lds_release();
             if (lane == 0) {
-                sweep_progress[wave] = wanted;
+                lds_flag_store(&sweep_progress[wave], wanted);
             }
+        }
+    };
+    // `value` "depends" on the accumulators: what is computed from it (the
+    // addresses of a refill) stays behind the FMAs that produce them
+    const auto order_after = [](index_type &value, ar_type (&sums)[NI]) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            asm volatile("" : "+v"(value) : "v"(sums[k]));
         }
     };
     if (!worker) {
@@ -1112,27 +1245,38 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
                     const std::int32_t wanted = static_cast<std::int32_t>(p) + 1;
                     // the slot still holds panel p - XK: wait until every
                     // worker has read it
+                    bool gave_up = false;
                     if (p >= XK) {
                         const std::int32_t need = wanted - XK;
                         while (!__all(lane >= Waves ||
-                                      sweep_progress[lane < Waves ? lane : 0] >=
-                                          need) &&
-                               !detail::spin_expired(spins, helper)) {
+                                      lds_flag_load(&sweep_progress[lane < Waves ? lane : 0]) >=
+                                          need)) {
+                            if (lds_flag_load(&relay_abort) != 0 ||
+                                detail::spin_expired(spins, helper)) {
+                                gave_up = true;
+                                break;
+                            }
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        lds_acquire();
                     }
-                    while (!__all(io::ready(raw[i], epoch)) &&
-                           !detail::spin_expired(spins, helper)) {
+                    while (!gave_up && !__all(io::ready(raw[i], epoch))) {
+                        if (detail::spin_expired(spins, helper)) {
+                            gave_up = true;
+                            break;
+                        }
                         __builtin_amdgcn_s_sleep(1);
                         io::load(granules, p * B + lane, raw[i]);
+                    }
+                    if (gave_up) {
+                        lds_flag_store(&relay_abort, 1);  // the workers stop waiting
                     }
                     x_ring[slot][lane] =
                         static_cast<ar_type>(io::decode(raw[i]));
                     // LDS operations of one wave complete in order: data,
                     // then the tag
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    lds_release();
                     if (lane == 0) {
-                        x_ring_tag[slot] = wanted;
+                        lds_flag_store(&x_ring_tag[slot], wanted);
                     }
                 }
             }
@@ -1150,7 +1294,28 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
                 issue(d, ring[d]);
             }
         }
-        for (index_type cb0 = 0; cb0 < far_end; cb0 += depth) {
+        index_type cb0 = 0;
+        if constexpr (Relay) {
+            // Whole groups of `depth` panels that all have a successor in the
+            // ring: no condition around the refill, so a slot's new loads land
+            // in the slot's own registers (a conditional refill is a phi of
+            // "loaded" and "kept": the compiler loads into other registers and
+            // copies them over at the join, behind a full wait), and the refill
+            // is kept BEHIND the panel's FMAs (`order_after`: issued ahead of
+            // them it would need other registers again). The waits in front of
+            // a panel's FMAs then read `vmcnt((depth - 1) * NI)`: the ring is
+            // `depth` panels deep in time (tests/test_isa_guard.py).
+            for (; cb0 + 2 * depth <= far_end; cb0 += depth) {
+#pragma unroll
+                for (int d = 0; d < depth; ++d) {
+                    consume(cb0 + d, ring[d]);
+                    index_type next = cb0 + d + depth;
+                    order_after(next, acc);
+                    issue(next, ring[d]);
+                }
+            }
+        }
+        for (; cb0 < far_end; cb0 += depth) {
 #pragma unroll
             for (int d = 0; d < depth; ++d) {
                 const index_type cb = cb0 + d;
@@ -1178,6 +1343,11 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
         ACCBLAS_TRSV_STAMP(block, 2);  // wave 0 finished its far sweep share
     }
     __syncthreads();
+    if (Relay && threadIdx.x == 0 && lds_flag_load(&relay_abort) != 0) {
+        // (whoever gave up: the caller must see that the solution is invalid)
+        __hip_atomic_store(helper, detail::trsv_error_word, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // ---- tail: c = inv(T) rhs_far (before the wait), then x = c - M x_{b-1} -
     // Both are 64 x 64 mat-vecs from LDS with lane = row. The columns are
@@ -1188,7 +1358,7 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     if (wave == 0) {
         ACCBLAS_TRSV_STAMP(block, 3);  // all waves finished the far sweep
     }
-    ar_type rhs = own_valid ? own_rhs - correction[lane] : ar_type{};
+    ar_type rhs = own_valid ? own_lds[lane] - correction[lane] : ar_type{};
     if (worker) {
         // every wave holds the full right-hand side (lane = row); entry
         // wave*CW + j of it multiplies column wave*CW + j of the inverse
@@ -1257,33 +1427,20 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
         ACCBLAS_TRSV_STAMP(block, 5);  // published
         ACCBLAS_TRSV_CYCLES(block, 12);
     }
-    // ---- re-arm the workspace for the next solve (off the critical path) ---
-    // A block is done with the workspace once its solution is published; the
-    // last one to say so is alone and resets the counters for its successor.
-    __shared__ bool is_last;
-    if (threadIdx.x == 0) {
-        const unsigned int done = __hip_atomic_fetch_add(
-            &session.state->finished, 1u, __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT);
-        is_last = done == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (is_last) {
-        std::uint32_t next_epoch = epoch + 1;
-        if (next_epoch == 0) {
-            // 2^32 solves on this workspace: stale tags could repeat
-            for (index_type i = threadIdx.x; i < session.capacity_words;
-                 i += blockDim.x) {
-                __hip_atomic_store(granules + i, granule_word{0},
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            next_epoch = trsv_first_epoch;
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            detail::rearm_state(session.state, next_epoch);
+#ifdef ACCBLAS_TRSV_DIAG
+    if (threadIdx.x == 0 && trsv_diag_buffer != nullptr) {
+        for (int i = 0; i < 16; ++i) {
+            trsv_diag_buffer[block * 16 + i] = diag_stamp[i];
         }
     }
+#endif
+    // ---- this block is done with the workspace (off the critical path) ----
+    count_event(epoch);
+    if constexpr (!persistent) {
+        return;
+    }
+    __syncthreads();  // the next block re-initialises what lives in LDS
+    }  // for (;;)
 }
 
 
@@ -1335,7 +1492,7 @@ constexpr unsigned trsv_single_block_pad()
     // underestimate is harmless (more padding), an overestimate is not
     constexpr std::size_t static_bytes =
         sizeof(ArType) *
-            (2 * B * (B + 1) + 2 * B + 2 * Waves * B + (Relay ? 16 * B : 0)) +
+            (2 * B * (B + 1) + 3 * B + 2 * Waves * B + (Relay ? 16 * B : 0)) +
         16;
     constexpr std::size_t needed = 160 * 1024 / 2 + 2048;
     return static_bytes >= needed
@@ -1344,11 +1501,22 @@ constexpr unsigned trsv_single_block_pad()
 }
 
 
-/** When the far sweep's x goes through the loader wave and LDS (measured,
- *  profiles/r01_trsv_relay_ab.txt). `relay_mode` of `launch_trsv` (option
- *  "trsv_relay" of accblas_set_option): 0 never, 1 by this rule, 2 always. */
+/** When the far sweep's x goes through the loader wave and LDS. `relay_mode`
+ *  of `launch_trsv` (option "trsv_relay" of accblas_set_option): 0 never, 1 by
+ *  this rule, 2 always. 2-byte storage and fp32 arithmetic: always (round 1,
+ *  profiles/r01_trsv_relay_ab.txt). fp64 arithmetic: from these sizes on. In
+ *  round 1 the relay lost there at every size; its workers then waited for each
+ *  panel they had just requested (see `consume`). With the ring in flight
+ *  (round 4, profiles/r04_trsv_relay_ring.txt, us, relay | direct): 8-byte
+ *  storage 512 18.2 | 17.6, 1024 27.2 | 29.2, 1500 35.4 | 44.2, 2048 44.5 |
+ *  52.9, 8192 160 | 222, 16384 329 | 461; 4-byte storage 1024 26.3 | 24.7, 2048
+ *  42.9 | 44.2, 3000 57.7 | 65.6, 4096 72.1 | 74.9 (from there the 128-row
+ *  kernel takes over), 24000 431 | 475, 65536 1614 | 2208. */
 #ifndef ACCBLAS_TRSV_RELAY_MIN_N
-#define ACCBLAS_TRSV_RELAY_MIN_N 17000
+#define ACCBLAS_TRSV_RELAY_MIN_N 2048
+#endif
+#ifndef ACCBLAS_TRSV_RELAY_MIN_N_8BYTE
+#define ACCBLAS_TRSV_RELAY_MIN_N_8BYTE 1024
 #endif
 constexpr index_type trsv_relay_min_n = ACCBLAS_TRSV_RELAY_MIN_N;
 
@@ -1363,7 +1531,7 @@ template <typename ArType, typename MtxView, typename XView>
 hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
                        const XView &x, std::uint32_t *helper,
                        const trsv_session &session, hipStream_t stream,
-                       int relay_mode = 1)
+                       int relay_mode = 1, int num_cus = 0)
 {
     using mtx_traits = view_traits<MtxView>;
     using st_type =
@@ -1379,17 +1547,16 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     constexpr int waves = trsv_waves;
     constexpr int vec16 = 16 / sizeof(st_type);
     // x through the loader wave and LDS (one more wave per workgroup) where
-    // it was measured to pay (profiles/r01_trsv_relay_ab.txt): the granule
-    // stream it removes weighs 8 bytes per element and worker, so it wins
-    // big for fp16 storage (-20...-27 % time), for fp64 storage once there
-    // are more blocks than CUs (-8...-15 %) and a little for fp32 arithmetic;
-    // fp64 arithmetic on fp32 storage is faster without the detour at every
-    // size
+    // it was measured to pay: the granule stream it removes weighs 8 bytes per
+    // element and worker, and the workers' memory queues hold nothing but
+    // their matrix panels (see `trsv_relay_min_n`)
     constexpr bool half_storage = sizeof(st_type) == 2;
     constexpr bool double_storage = sizeof(st_type) == 8;
     constexpr bool float_arithmetic = std::is_same<ArType, float>::value;
-    const bool by_rule = half_storage || float_arithmetic ||
-                         (double_storage && n >= trsv_relay_min_n);
+    const bool by_rule =
+        half_storage || float_arithmetic ||
+        n >= (double_storage ? index_type{ACCBLAS_TRSV_RELAY_MIN_N_8BYTE}
+                             : trsv_relay_min_n);
     const bool relay = relay_mode == 2 || (relay_mode == 1 && by_rule);
     const dim3 block((waves + (relay ? 1 : 0)) * wave_size, 1, 1);
     const unsigned pad = relay ? trsv_single_block_pad<ArType, waves, true>()
@@ -1398,18 +1565,33 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     const bool vec_ok = is_aligned(mtx_traits::data(mtx), 16) &&
                         mtx_traits::stride(mtx) % vec16 == 0;
     // (the vector path of an upper solve is laid out for a virtual size)
-    const dim3 grid(
+    // one workgroup per row block, but no more than one per CU: workgroups
+    // draw tickets until none is left (see the kernel)
+    const unsigned row_blocks =
         trsv_num_blocks(n + (vec_ok && vec16 > 1
                                  ? trsv_virtual_pad<st_type>(upper, n)
-                                 : index_type{0})),
-        1, 1);
+                                 : index_type{0}));
+    const bool persistent =
+        num_cus > 0 && row_blocks > static_cast<unsigned>(num_cus);
+    const dim3 grid(persistent ? static_cast<unsigned>(num_cus) : row_blocks,
+                    1, 1);
 #define ACCBLAS_TRSV_LAUNCH_RELAY(_upper, _unit, _relay)                       \
     if (vec_ok) {                                                              \
-        kernel::trsv<waves, _upper, _unit, vec16, _relay, ArType>              \
-            <<<grid, block, pad, stream>>>(mtx, x, helper, session);           \
+        if (persistent) {                                                      \
+            kernel::trsv<waves, _upper, _unit, vec16, _relay, ArType, true>    \
+                <<<grid, block, pad, stream>>>(mtx, x, helper, session);       \
+        } else {                                                               \
+            kernel::trsv<waves, _upper, _unit, vec16, _relay, ArType, false>   \
+                <<<grid, block, pad, stream>>>(mtx, x, helper, session);       \
+        }                                                                      \
     } else {                                                                   \
-        kernel::trsv<waves, _upper, _unit, 1, _relay, ArType>                  \
-            <<<grid, block, pad, stream>>>(mtx, x, helper, session);           \
+        if (persistent) {                                                      \
+            kernel::trsv<waves, _upper, _unit, 1, _relay, ArType, true>        \
+                <<<grid, block, pad, stream>>>(mtx, x, helper, session);       \
+        } else {                                                               \
+            kernel::trsv<waves, _upper, _unit, 1, _relay, ArType, false>       \
+                <<<grid, block, pad, stream>>>(mtx, x, helper, session);       \
+        }                                                                      \
     }
 #define ACCBLAS_TRSV_LAUNCH(_upper, _unit)                                     \
     if (relay) {                                                               \

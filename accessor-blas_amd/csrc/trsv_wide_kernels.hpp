@@ -81,6 +81,10 @@ struct trsv_wide_split {
     // into the Infinity Cache ahead of the chain's front (see
     // `detail::prefetch_ahead`)
     int prefetchers;
+    // Tickets of the solve (solving workgroups + prefetchers): what
+    // `trsv_wide_grid` returns. A launch may have fewer workgroups than
+    // tickets (one per CU): they draw tickets until none is left.
+    int tickets;
 };
 constexpr int trsv_wide_max_parts = trsv_partial_slots + 1;
 // helpers' sums an owner takes through LDS at a time
@@ -332,7 +336,8 @@ __device__ __forceinline__ T inverse_row_times(const T *x00, const T *x11,
  * panel W is not yet computed (long sweeps defer it).
  */
 template <bool Upper, bool UnitDiag, int Vec, int PanelCols, int Depth,
-          int DeepDepth, typename ArType, typename MtxView, typename XView>
+          int DeepDepth, typename ArType, bool Persistent = false,
+          typename MtxView, typename XView>
 __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     MtxView mtx, XView x, std::uint32_t *helper, trsv_session session,
     trsv_wide_split split)
@@ -384,8 +389,27 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     __shared__ std::uint32_t shared_epoch;
     __shared__ bool is_last;
 
-    const int lane = lane_id();
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave_id());
+    // Persistent = true: the launch has one workgroup per CU and fewer
+    // workgroups than tickets; a workgroup draws tickets until none is left
+    // (see `kernel::trsv`: row blocks beyond the CU count would otherwise wait
+    // for the hardware dispatcher, which binds workgroup k to XCD k mod 8).
+    // Events the last of which re-arms the workspace: every ticket's work done
+    // and, when persistent, every workgroup's final draw.
+    const unsigned int total_tickets = static_cast<unsigned int>(split.tickets);
+    const unsigned int last_event =
+        Persistent ? total_tickets + gridDim.x - 1 : total_tickets - 1;
+    const int lane_of_thread = lane_id();
+    const int wave_of_thread = wave_id();
+    for (;;) {
+    // (made opaque once per ticket: what the body computes from the lane is
+    // invariant in this loop and would be computed - and kept - in front of it)
+    int lane_now = lane_of_thread;
+    int wave_now = wave_of_thread;
+    if constexpr (Persistent) {
+        asm volatile("" : "+v"(lane_now), "+v"(wave_now));
+    }
+    const int lane = lane_now;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave_now);
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
     unsigned long long diag_stamp[20] = {};
     unsigned long long diag_poll_issue = 0;   // last probe issued by poll_finish
@@ -414,8 +438,12 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                                 session.granules, session.capacity_words);
         // (a ticket that could not be had - ~0u - maps to a block beyond the
         // matrix: the workgroup leaves, helper[0] says why)
+        // (~0u: the wait for a ticket gave up; beyond the last ticket:
+        // nothing left to do)
         const unsigned int ticket =
-            drawn.ticket < gridDim.x ? drawn.ticket : 0x3fffffffu;
+            drawn.ticket < total_tickets
+                ? drawn.ticket
+                : (drawn.ticket == ~0u ? 0x3fffffffu : 0x3ffffffdu);
         shared_epoch = drawn.epoch;
         // tickets -> (row block, part): blocks below split.first_block have one
         // workgroup; each later block has `parts`, its helpers first and its
@@ -423,13 +451,14 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         std::int32_t ticket_block = static_cast<std::int32_t>(ticket);
         std::int32_t ticket_part = 0;
         const unsigned int solvers =
-            gridDim.x - static_cast<unsigned int>(split.prefetchers);
-        if (ticket < gridDim.x && ticket >= solvers) {
+            total_tickets - static_cast<unsigned int>(split.prefetchers);
+        if (ticket < total_tickets && ticket >= solvers) {
             // the last tickets do not solve (`trsv_wide_split::prefetchers`)
             ticket_block = detail::trsv_wide_prefetch_block;
             ticket_part = static_cast<std::int32_t>(ticket - solvers);
         }
-        if (split.parts > 1 && ticket_block >= split.first_block &&
+        if (split.parts > 1 && ticket < total_tickets &&
+            ticket_block >= split.first_block &&
             ticket_block != detail::trsv_wide_prefetch_block) {
             const std::int32_t beyond = ticket_block - split.first_block;
             const std::int32_t body =
@@ -474,7 +503,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             const unsigned int done = __hip_atomic_fetch_add(
                 &session.state->finished, 1u, __ATOMIC_RELAXED,
                 __HIP_MEMORY_SCOPE_AGENT);
-            is_last = done == gridDim.x - 1;
+            is_last = done == last_event;
         }
         __syncthreads();
         if (is_last) {
@@ -493,18 +522,27 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             }
         }
     };
+    if (block == 0x3ffffffd) {
+        finish();  // this workgroup's final draw
+        return;
+    }
+    if (block == 0x3fffffff) {
+        return;  // no ticket to be had: helper[0] says why
+    }
     if (block == detail::trsv_wide_prefetch_block) {
         detail::prefetch_ahead<Upper, R>(mtx_traits::data(mtx),
                                          mtx_traits::stride(mtx), n,
                                          session.state, helper, shared_part,
                                          split.prefetchers);
         finish();
-        return;
+        if constexpr (Persistent) {
+            __syncthreads();
+            continue;
+        } else {
+            return;
+        }
     }
     const index_type base = block * R;
-    if (base >= n) {
-        return;  // cannot happen: the grid covers exactly ceil(n / R) blocks
-    }
     // Split row blocks. A solve with more row blocks than CUs ends with the
     // blocks that have the MOST far columns starting LAST (when a CU frees up),
     // each streaming tens of MB alone while more and more CUs idle: at
@@ -1311,6 +1349,11 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
 #endif
 
     finish();
+    if constexpr (!Persistent) {
+        return;
+    }
+    __syncthreads();  // the next ticket's work re-uses what lives in LDS
+    }  // for (;;)
 }
 
 
@@ -1429,15 +1472,17 @@ inline trsv_wide_split trsv_wide_split_for(index_type n, int num_cus,
                                ACCBLAS_TRSV_WIDE_TAIL_DEFERRED,
                                blocks - last_blocks,
                                last_blocks > 0 ? ACCBLAS_TRSV_WIDE_LAST_PARTS : 1,
+                               0,
                                0};
     }
     return trsv_wide_split{blocks, 1, blocks, 1,
                            static_cast<int>(trsv_wide_deferred_columns), blocks,
-                           1, 0};
+                           1, 0, 0};
 }
 
-/** Workgroups a solve launches under `split`. */
-inline unsigned trsv_wide_grid(index_type n, const trsv_wide_split &split)
+/** Tickets (units of work: row blocks, helpers' shares, prefetchers) of a
+ *  solve under `split`. */
+inline unsigned trsv_wide_tickets(index_type n, const trsv_wide_split &split)
 {
     const index_type blocks = ceildiv(n, index_type{trsv_wide_rows});
     return static_cast<unsigned>(
@@ -1454,8 +1499,10 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
                                   std::uint32_t *helper,
                                   const trsv_session &session,
                                   hipStream_t stream,
-                                  const trsv_wide_split &split)
+                                  const trsv_wide_split &split_in,
+                                  int num_cus = 0)
 {
+    trsv_wide_split split = split_in;
     using st_type =
         std::remove_cv_t<typename view_traits<XView>::storage_type>;
     static_assert(view_traits<MtxView>::is_pointer_view &&
@@ -1509,13 +1556,40 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
     // (`defer_fold`, helpers of split blocks): as deep as the registers allow.
     constexpr int depth = sizeof(st_type) == 2 ? 3 : 2;
     constexpr int deep_depth = sizeof(st_type) == 2 ? 5 : 4;
-    const dim3 grid(trsv_wide_grid(n, split));
+    const unsigned tickets = trsv_wide_tickets(n, split);
+    split.tickets = static_cast<int>(tickets);
+    // one workgroup per ticket, but no more than one per CU: the workgroups
+    // then draw tickets until none is left (`Persistent`)
+    // (the persistent form of THIS kernel is only built on request,
+    // -DACCBLAS_TRSV_WIDE_PERSISTENT: the loop around the row block costs it
+    // 170 spilled registers, profiles/r04_trsv_persistent.txt)
+#ifdef ACCBLAS_TRSV_WIDE_PERSISTENT
+    const bool persistent =
+        num_cus > 0 && tickets > static_cast<unsigned>(num_cus);
+#else
+    const bool persistent = false;
+    (void)num_cus;
+#endif
+    const dim3 grid(persistent ? static_cast<unsigned>(num_cus) : tickets);
     const dim3 block(trsv_wide_waves * wave_size);
     const unsigned pad = trsv_wide_single_block_pad<ArType>();
+#ifdef ACCBLAS_TRSV_WIDE_PERSISTENT
+#define ACCBLAS_TRSV_WIDE_LAUNCH(_upper, _unit)                                \
+    if (persistent) {                                                          \
+        kernel::trsv_wide<_upper, _unit, vec16, panel_cols, depth, deep_depth, \
+                          ArType, true>                                        \
+            <<<grid, block, pad, stream>>>(mtx, x, helper, session, split);    \
+    } else {                                                                   \
+        kernel::trsv_wide<_upper, _unit, vec16, panel_cols, depth, deep_depth, \
+                          ArType, false>                                       \
+            <<<grid, block, pad, stream>>>(mtx, x, helper, session, split);    \
+    }
+#else
 #define ACCBLAS_TRSV_WIDE_LAUNCH(_upper, _unit)                                \
     kernel::trsv_wide<_upper, _unit, vec16, panel_cols, depth, deep_depth,     \
-                      ArType>                                                  \
+                      ArType, false>                                           \
         <<<grid, block, pad, stream>>>(mtx, x, helper, session, split)
+#endif
     if (upper) {
         if (unit_diag) {
             ACCBLAS_TRSV_WIDE_LAUNCH(true, true);
@@ -1558,7 +1632,7 @@ hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
                             const XView &x, std::uint32_t *helper,
                             const trsv_session &session, hipStream_t stream,
                             int num_cus, int split_from = 0,
-                            int prefetch_mode = 1)
+                            int prefetch_mode = 1, int persistent_mode = 0)
 {
     using st_type =
         std::remove_cv_t<typename view_traits<XView>::storage_type>;
@@ -1570,7 +1644,8 @@ hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
                                laid_out, num_cus, prefetch_mode)
                          : 0;
     return launch_trsv_wide_split<ArType>(upper, unit_diag, mtx, x, helper,
-                                          session, stream, split);
+                                          session, stream, split,
+                                          persistent_mode != 0 ? num_cus : 0);
 }
 
 

@@ -367,6 +367,44 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+/** Release / acquire between the waves of a workgroup for data that lives in
+ *  LDS: a wave's LDS operations are served in order, so "every earlier LDS
+ *  operation of this wave has been performed" (release) is one wait on the LDS
+ *  counter and "later LDS reads see what the writer wrote before the flag"
+ *  (acquire) needs no instruction at all - both only have to keep the COMPILER
+ *  from moving LDS accesses across them. `__builtin_amdgcn_fence(...,
+ *  "workgroup")` also waits for the wave's outstanding GLOBAL loads
+ *  (`s_waitcnt vmcnt(0)`): in a sweep that keeps matrix prefetches in flight
+ *  that is one full memory latency per step. */
+__device__ __forceinline__ void lds_release()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void lds_acquire()
+{
+    asm volatile("" ::: "memory");
+}
+
+/** A 32-bit flag in LDS that waves of a workgroup poll / raise. Relaxed
+ *  workgroup-scope atomics compile to `ds_read_b32` / `ds_write_b32`; a
+ *  `volatile __shared__` object reached through a reference (a lambda capture)
+ *  is accessed with FLAT loads instead - the address-space inference leaves
+ *  volatile accesses alone -, and a flat load counts in `vmcnt`: every look at
+ *  the flag then waits for all the global loads the wave has in flight. */
+__device__ __forceinline__ std::int32_t lds_flag_load(const std::int32_t *flag)
+{
+    return __hip_atomic_load(flag, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__device__ __forceinline__ void lds_flag_store(std::int32_t *flag,
+                                               std::int32_t value)
+{
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 /** Drains this wave's outstanding vector-memory operations. Written as asm
  *  so the compiler cannot drop it in front of a flag/ticket update (guide:
  *  'Compiler hazard'). */

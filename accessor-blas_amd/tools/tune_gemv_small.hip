@@ -80,6 +80,10 @@ static bool fine_pass = false;
 // the reference allocates max_size x max_size (2.4 GB of fp32 at 24500): small
 // blocks of a large allocation run slower than the same blocks of a small one
 static bool big_matrix = false;
+// "mall": production and two finer shapes with and without the non-temporal
+// hint on the matrix loads, n = 3000 ... 12000 (the matrix fits the 256 MiB
+// Infinity Cache up to n = 8000 with 4-byte and 5600 with 8-byte storage)
+static bool mall_pass = false;
 
 template <typename Ar, typename St>
 void sweep(const char *title, long lda, int reps, rocblas_handle blas)
@@ -89,7 +93,7 @@ void sweep(const char *title, long lda, int reps, rocblas_handle blas)
     using c_range = gko::acc::range<typename accessor::const_accessor>;
     using sz = std::array<gko::acc::size_type, 2>;
     using st = std::array<gko::acc::size_type, 1>;
-    const long max_n = big_matrix ? lda : (fine_pass ? 24000 : 6000);
+    const long max_n = big_matrix ? lda : (fine_pass ? 24000 : (mall_pass ? 12000 : 6000));
     St *A, *x, *res;
     CHECK(hipMalloc(&A, size_t(max_n) * lda * sizeof(St)));
     CHECK(hipMalloc(&x, lda * sizeof(St)));
@@ -108,8 +112,27 @@ void sweep(const char *title, long lda, int reps, rocblas_handle blas)
                                Ar(1), m, xv, Ar(1), rv, nullptr,               \
                                gemv_skew_mode::never)));                       \
                        }});
+#define ADDC(W, WPR, R, U)                                                     \
+    entries.push_back({"w" #W "p" #WPR "r" #R "u" #U "c", [=](long n, long nc) { \
+                           c_range m(sz{{n, nc}}, (const St *)A, st{{lda}});   \
+                           c_range xv(sz{{nc, 1}}, (const St *)x, st{{1}});    \
+                           range rv(sz{{n, 1}}, res, st{{1}});                 \
+                           CHECK((launch_gemv<gemv_config<W, WPR, R, U, false>>( \
+                               Ar(1), m, xv, Ar(1), rv, nullptr,               \
+                               gemv_skew_mode::never)));                       \
+                       }});
     ADD(8, 4, 4, 2)  // production shape
-    if (big_matrix) {
+    if (mall_pass) {
+        ADDC(8, 4, 4, 2)
+        ADD(8, 4, 2, 2)
+        ADDC(8, 4, 2, 2)
+        ADD(4, 2, 2, 2)
+        ADDC(4, 2, 2, 2)
+        ADD(4, 4, 2, 1)
+        ADDC(4, 4, 2, 1)
+        ADD(2, 2, 1, 2)
+        ADDC(2, 2, 1, 2)
+    } else if (big_matrix) {
         ADD(2, 2, 1, 2)
         ADD(2, 2, 1, 4)
         ADD(2, 2, 1, 8)
@@ -156,6 +179,7 @@ void sweep(const char *title, long lda, int reps, rocblas_handle blas)
     ADD(1, 1, 2, 2)
     }
 #undef ADD
+#undef ADDC
     // the same call through the C ABI of the library (what the CLI times)
     entries.push_back({"library", [=](long n, long nc) {
         const accblas_dtype ar = sizeof(Ar) == 8 ? ACCBLAS_F64 : ACCBLAS_F32;
@@ -186,7 +210,9 @@ void sweep(const char *title, long lda, int reps, rocblas_handle blas)
     }});
 
     const std::vector<long> sizes =
-        fine_pass ? std::vector<long>{2000, 3000, 3100, 3300, 3500, 4000, 4100, 4500, 5000, 5200,
+        mall_pass ? std::vector<long>{1000, 2000, 3000, 3500, 4000, 4500, 5000, 5500, 6000, 6500, 7000,
+                                      7500, 8000, 8500, 9000, 10000, 11000, 12000}
+        : fine_pass ? std::vector<long>{2000, 3000, 3100, 3300, 3500, 4000, 4100, 4500, 5000, 5200,
                                       5500, 6000, 6200, 6500, 7000, 8000, 8200, 10000, -1000,
                                       -2000, -3000, -4000}
                   : std::vector<long>{100,  500,  900,  1100, 1300, 1600, 1900, 2200,
@@ -231,6 +257,7 @@ int main(int argc, char **argv)
     fine_pass = argc > 3 && std::string(argv[3]) == "fine";
     fresh_events = argc > 3 && std::string(argv[3]) == "fresh";
     big_matrix = argc > 3 && std::string(argv[3]) == "big";
+    mall_pass = argc > 3 && std::string(argv[3]) == "mall";
     CHECK(hipEventCreate(&ev_start));
     CHECK(hipEventCreate(&ev_stop));
     rocblas_handle blas;

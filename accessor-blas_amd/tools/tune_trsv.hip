@@ -81,10 +81,10 @@ int main(int argc, char **argv)
     };
     std::vector<entry> entries = {
         // 8 worker waves + the loader wave = 576 threads
-        make("direct 2/CU", kernel::trsv<8, false, true, 4, false, ar_type, c_range, range>, 512, 0),
-        make("direct 1/CU", kernel::trsv<8, false, true, 4, false, ar_type, c_range, range>, 512, 40000),
-        make("relay 1/CU", kernel::trsv<8, false, true, 4, true, ar_type, c_range, range>, 576, 40000),
-        make("direct vec1 1/CU", kernel::trsv<8, false, true, 1, false, ar_type, c_range, range>, 512, 40000),
+        make("direct 2/CU", kernel::trsv<8, false, true, 4, false, ar_type, false, c_range, range>, 512, 0),
+        make("direct 1/CU", kernel::trsv<8, false, true, 4, false, ar_type, false, c_range, range>, 512, 40000),
+        make("relay 1/CU", kernel::trsv<8, false, true, 4, true, ar_type, false, c_range, range>, 576, 40000),
+        make("direct vec1 1/CU", kernel::trsv<8, false, true, 1, false, ar_type, false, c_range, range>, 512, 40000),
     };
     hipEvent_t start, stop;
     CHECK(hipEventCreate(&start));

@@ -164,12 +164,16 @@ int main(int argc, char **argv)
                         "worst lateness %.1f us, last published at %.1f\n",
                         rec == &*fastest ? "fastest" : "slowest", rec->us, late,
                         late_after_256, worst_wait, us(blocks - 1, 5));
-            std::printf("    block: ticket  staged  M_ready  far_done  seen  published | hop(avg of 16)  far_done-prev_pub\n");
+            std::printf("    block: ticket  staged  M_ready  far_done  seen  published | hop(avg of 16)  far_done-prev_pub | first wait in the sweep: at, panel, front then\n");
             for (unsigned b = 0; b < blocks; b += 16) {
                 const double hop16 = b >= 16 ? (us(b, 5) - us(b - 16, 5)) / 16 : 0.0;
-                std::printf("    %5u: %7.1f %7.1f %7.1f %8.1f %8.1f %8.1f | %5.2f  %7.1f\n", b,
+                // where the chain's front was when this block first had to wait for x
+                unsigned front = 0;
+                const double waited = s[b * 16 + 13] ? us(b, 13) : -1.0;
+                while (waited >= 0 && front + 1 < blocks && us(front, 5) < waited) ++front;
+                std::printf("    %5u: %7.1f %7.1f %7.1f %8.1f %8.1f %8.1f | %5.2f  %7.1f | %8.1f %5llu %5u\n", b,
                             us(b, 0), us(b, 10), us(b, 6), us(b, 3), us(b, 4), us(b, 5), hop16,
-                            b ? us(b, 3) - us(b - 1, 5) : 0.0);
+                            b ? us(b, 3) - us(b - 1, 5) : 0.0, waited, s[b * 16 + 14], front);
             }
         }
     }
