@@ -13,6 +13,7 @@
 
 #include "accblas_internal.hpp"
 #include "trsv_kernels.hpp"
+#include "trsv_small_kernels.hpp"
 #include "trsv_wide_kernels.hpp"
 
 
@@ -68,6 +69,9 @@ int trsv_split_from_option_value();
 int trsv_prefetch_option_value();
 /** Option "trsv_relay": 0 never, 1 by the measured rule (default), 2 always. */
 int trsv_relay_option_value();
+/** Option "trsv_small": 0 = the blocked kernels at every size, 1 = systems of
+ *  at most 128 unknowns by one workgroup without a workspace (default). */
+int trsv_small_option_value();
 
 /** Where the 128-row kernel is the faster one. 2- and 4-byte storage: from
  *  n = 4096 on (profiles/r02_trsv_ab_final.txt: 4-7 % faster at 4096, 17-20 % at
@@ -118,6 +122,14 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
             return status;
         }
         session = lease.session();
+    }
+    if (n <= dev::trsv_small_max_n && trsv_small_option_value() != 0) {
+        // one workgroup, nothing handed over through memory: the workspace
+        // (library-owned or the caller's) stays untouched
+        return check_hip(dev::launch_trsv_small<ar_type>(upper, unit_diag, mtx,
+                                                         x, helper,
+                                                         as_stream(stream)),
+                         "trsv (one workgroup) launch");
     }
     // the key the launch's workgroups recognise each other by (`trsv_state`)
     session.serial = dev::trsv_next_serial();

@@ -85,6 +85,11 @@ struct trsv_wide_split {
     // `trsv_wide_grid` returns. A launch may have fewer workgroups than
     // tickets (one per CU): they draw tickets until none is left.
     int tickets;
+    // Do row blocks with a long far sweep fold their panel late (see
+    // `defer_fold` in the kernel)? Only where row blocks start late: with a
+    // CU for every row block (set by the launcher) all of them start with the
+    // solve and fold at once, while the chain is still far away.
+    int defer;
 };
 constexpr int trsv_wide_max_parts = trsv_partial_slots + 1;
 // helpers' sums an owner takes through LDS at a time
@@ -289,33 +294,48 @@ __device__ __forceinline__ T inverse_row_times(const T *x00, const T *x11,
     constexpr int H = 64;
     constexpr int columns = 16 * (Tile + 1);
     constexpr int runs = (columns + 31) / 32;
-    T entry[runs][8];
-    T right[runs][8];
-#pragma unroll
-    for (int m = 0; m < runs; ++m) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 32 * m + 8 * fk + j;
-            // (columns beyond the row's last tile exist in LDS - the same
-            // 64-column tile - and are masked out)
-            T value;
-            if (Tile < 4) {
-                value = x00[k * ld + row];
-            } else if (32 * m < H) {
-                value = x10[k * ld + row - H];
-            } else {
-                value = x11[(k - H) * ld + row - H];
-            }
-            entry[m][j] = (32 * m + 31 < columns || k < columns) ? value : T{};
-            right[m][j] = rhs[k];
-        }
-    }
+    // (two runs - 16 entries and 16 right-hand sides, 64 registers with fp64 -
+    // are read ahead of their FMAs at a time: all four at once made this the
+    // place where the kernel needs the most registers, and what is live across
+    // it - W, the row pointers of the sweep - paid for that with spills)
+    constexpr int batch = 2;
     T part[4] = {};
 #pragma unroll
-    for (int m = 0; m < runs; ++m) {
+    for (int m0 = 0; m0 < runs; m0 += batch) {
+        T entry[batch][8];
+        T right[batch][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            part[j & 3] += entry[m][j] * right[m][j];
+        for (int mb = 0; mb < batch; ++mb) {
+            const int m = m0 + mb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 32 * m + 8 * fk + j;
+                // (columns beyond the row's last tile exist in LDS - the same
+                // 64-column tile - and are masked out)
+                T value{};
+                if (m < runs) {
+                    if (Tile < 4) {
+                        value = x00[k * ld + row];
+                    } else if (32 * m < H) {
+                        value = x10[k * ld + row - H];
+                    } else {
+                        value = x11[(k - H) * ld + row - H];
+                    }
+                }
+                entry[mb][j] =
+                    (m < runs && (32 * m + 31 < columns || k < columns)) ? value
+                                                                          : T{};
+                right[mb][j] = m < runs ? rhs[k] : T{};
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < batch; ++mb) {
+            if (m0 + mb < runs) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    part[j & 3] += entry[mb][j] * right[mb][j];
+                }
+            }
         }
     }
     return (part[0] + part[1]) + (part[2] + part[3]);
@@ -775,7 +795,14 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     };
     // block columns that are swept after W has been computed when W is
     // deferred (W takes ~10 us; the chain's front must still be far away)
-    const bool defer_fold = block - 1 >= 2 * trsv_wide_deferred_columns;
+    // With every row block resident from the start (split.defer == 0) nothing
+    // is deferred: the block would follow the front through its bulk columns,
+    // fall 7-8 columns behind while it folds (~14 us), and catch up at one tile
+    // per memory latency - the pace of the chain itself - so the chain ends up
+    // waiting for it (16 us at block 97 of 188, n = 24000, 5 us at every ~10th
+    // block behind it: profiles/r04_trsv_wide_front.txt).
+    const bool defer_fold =
+        split.defer != 0 && block - 1 >= 2 * trsv_wide_deferred_columns;
     // (the owners of the last blocks start when the front has already passed
     // most of what they would keep, and sweep it with the shallow ring)
     const index_type deferred_columns =
@@ -1019,10 +1046,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         chunk_first = column;
         chunk_end_step = (column + count) * PPB;
     };
-    const auto consume = [&](index_type cb, stage &s) {
-        if (cb == chunk_end_step) {
-            next_chunk();
-        }
+    // step cb's matrix data times its x, which lies at `offset` in `x_chunk`
+    const auto apply = [&](index_type cb, stage &s, int offset) {
         if (Upper && cb == 0 && pad % Vec != 0) {
             // the vector across the first real column: what was loaded for
             // its virtual columns lies beyond the row's end
@@ -1038,9 +1063,6 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                 }
             }
         }
-        const int offset = static_cast<int>(cb / PPB - chunk_first) * R +
-                           static_cast<int>(cb % PPB) * PanelCols +
-                           col_group * Vec;
         ar_type xv[Vec];
 #pragma unroll
         for (int e = 0; e < Vec; ++e) {
@@ -1056,14 +1078,28 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                           xv[Upper ? Vec - 1 - e : e];
             }
         }
+    };
+    const auto consume = [&](index_type cb, stage &s) {
+        if (cb == chunk_end_step) {
+            next_chunk();
+        }
+        apply(cb, s,
+              static_cast<int>(cb / PPB - chunk_first) * R +
+                  static_cast<int>(cb % PPB) * PanelCols + col_group * Vec);
         // the poller's probe of the next column goes out before its prefetch
         if (cb + 1 == chunk_end_step && cb + 1 < far_end) {
             begin_probe((cb + 1) / PPB);
         }
     };
-    // steps [begin, end) with `depth_tag` steps of matrix data in flight
-    const auto sweep = [&](auto depth_tag, index_type begin, index_type end) {
+    // steps [begin, end) with `depth_tag` steps of matrix data in flight;
+    // returns the first step it has not consumed: `end`, or - `until_front_tag`
+    // = true - the step behind the one at which the workgroup reached the
+    // chain's front (what the ring holds beyond it is dropped: the front loop
+    // below requests it again)
+    const auto sweep = [&](auto depth_tag, auto until_front_tag,
+                           index_type begin, index_type end) -> index_type {
         constexpr int D = decltype(depth_tag)::value;
+        constexpr bool until_front = decltype(until_front_tag)::value;
         stage ring[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -1077,11 +1113,148 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                 const index_type cb = cb0 + d;
                 if (cb < end) {
                     consume(cb, ring[d]);
+                    if (until_front && at_front) {
+                        return cb + 1;
+                    }
                     if (cb + D < end) {
                         issue(cb + D, ring[d]);
                     }
                 }
             }
+        }
+        return end;
+    };
+    // `value` "depends" on the accumulators: what is computed from it (the
+    // addresses of a refill) stays behind the FMAs that produce them
+    const auto order_after = [](index_type &value, ar_type (&sums)[NI]) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            asm volatile("" : "+v"(value) : "v"(sums[k]));
+        }
+    };
+    // ---- the front loop: one block column per step, the chain's pace --------
+    // A workgroup at the front gets one block column of x per hop. Every block
+    // is such a follower until its turn, so a follower's turn-around per column
+    // bounds the hop. In the general sweep above it is one full latency of the
+    // workgroup's own 64 KB tile per column: the poll (vector-memory probes,
+    // spin loops with loads) and the refills of the ring share one instruction
+    // stream, the compiler cannot count what is outstanding and waits for
+    // everything - also for the tile it has just requested - before every step
+    // (profiles/r03_trsv_hop_paths.txt, addendum). Here the two jobs have code
+    // of their own:
+    //   * waves 1..7 (`Poller` = false): a loop with NO vector-memory operation
+    //     but the refills of their ring, whole groups of `Depth` steps without
+    //     a condition around the refill (it lands in the slot's own registers,
+    //     behind the step's FMAs): the wait in front of a step's FMAs counts
+    //     the newer refills, the ring is `Depth` tiles deep in time;
+    //   * wave 0 (`Poller` = true) polls. Probes return in order behind
+    //     whatever the wave has requested before, so it requests its share of
+    //     a tile only when it has SEEN the column before - nothing then stands
+    //     between two probes - and, so that this late request is served from
+    //     the L2 cache and not from HBM, wave 1 has touched those cache lines
+    //     one hop earlier (one extra load per step in wave 1's queue).
+    // Two LDS-only barriers per column as before. Same arithmetic, same order
+    // of summation as the general sweep.
+    const auto front_step = [&](auto poller_tag, index_type c, stage &slot,
+                                stage &previous, bool refill,
+                                std::uint32_t &touched,
+                                std::uint32_t &touched_word) {
+        constexpr bool Poller = decltype(poller_tag)::value;
+        lds_barrier();  // nobody reads the old column's x any more
+        if constexpr (Poller) {
+            ACCBLAS_TRSV_WIDE_STAMP(10);
+            if (!probe_pending) {
+                poll_begin(c * R + lane, probe0, probe1);
+            }
+            poll_finish(c * R + lane, probe0, probe1);
+            probe_pending = false;
+            ACCBLAS_TRSV_WIDE_STAMP(11);
+            if (lane == 0 && c + 1 == block) {
+                // (an unfolded block meets its predecessor here)
+                __hip_atomic_fetch_max(&session.state->front,
+                                       static_cast<unsigned int>(block),
+                                       __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            x_chunk[lane] = io::decode(probe0);
+            x_chunk[H + lane] = io::decode(probe1);
+            // this wave's share of the tile `Depth - 1` columns ahead, into
+            // the slot of the column consumed one step ago
+            if (c >= 1 && c - 1 + Depth < far_end) {
+                issue(c - 1 + Depth, previous);
+            }
+        }
+        lds_barrier();
+        apply(c, slot, col_group * Vec);
+        if constexpr (Poller) {
+            if (c + 1 < far_end) {
+                poll_begin((c + 1) * R + lane, probe0, probe1);
+                probe_pending = true;
+            }
+        } else {
+            if (wave_u == 1 && c + Depth < far_end) {
+                // wave 0's rows of the tile it will ask for one hop from now:
+                // one 4-byte load per 128-byte line (default cache policy)
+                constexpr int line_elements = 128 / static_cast<int>(sizeof(st_type));
+                constexpr int lines_per_row = PanelCols / line_elements;
+                static_assert(RW * lines_per_row <= wave_size, "one load covers wave 0's rows");
+                if (lane < RW * lines_per_row) {
+                    const index_type gr = base + lane / lines_per_row;
+                    const index_type first_col =
+                        (c + Depth) * PanelCols + (lane % lines_per_row) * line_elements;
+                    const index_type mem_col =
+                        Upper ? n - 1 - (first_col + line_elements - 1) : first_col;
+                    // (the value is looked at one step later: looked at here,
+                    // the wait for it would be a wait for every refill in flight)
+                    touched ^= touched_word;
+                    st_type value = a_data[phys(inside(gr)) * lda + (mem_col > 0 ? mem_col : 0)];
+                    touched_word = 0;
+                    __builtin_memcpy(&touched_word, &value, sizeof(st_type) < 4 ? sizeof(st_type) : 4);
+                }
+            }
+            if (refill) {
+                index_type next = c + Depth;
+                order_after(next, acc);
+                issue(next, slot);
+            }
+        }
+    };
+    const auto front_sweep = [&](auto poller_tag, index_type begin,
+                                 index_type end) {
+        constexpr bool Poller = decltype(poller_tag)::value;
+        constexpr int D = Depth;
+        stage ring[D];
+        std::uint32_t touched = 0;
+        std::uint32_t touched_word = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            // (the poller's share of step begin + D - 1 is requested by its
+            // first step, as of every later one)
+            if (begin + d < end && !(Poller && d == D - 1 && begin >= 1)) {
+                issue(begin + d, ring[d]);
+            }
+        }
+        index_type cb0 = begin;
+        for (; cb0 + 2 * D <= end; cb0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                front_step(poller_tag, cb0 + d, ring[d], ring[(d + D - 1) % D],
+                           true, touched, touched_word);
+            }
+        }
+        for (; cb0 < end; cb0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (cb0 + d < end) {
+                    front_step(poller_tag, cb0 + d, ring[d],
+                               ring[(d + D - 1) % D], cb0 + d + D < end, touched,
+                               touched_word);
+                }
+            }
+        }
+        touched ^= touched_word;
+        if (touched == 0x5a17c0deu && spins == 0x7fffffffu) {
+            helper[1] = touched;  // never: keeps wave 1's touching loads alive
         }
     };
     index_type swept = first_column * PPB;
@@ -1091,7 +1264,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         // the owner as tagged granules (this path must not run into the
         // owner's code below: the compiler would keep the owner's registers
         // alive across the helper's deep ring)
-        sweep(std::integral_constant<int, DeepDepth>{}, swept, far_end);
+        sweep(std::integral_constant<int, DeepDepth>{}, std::false_type{}, swept,
+              far_end);
         const ar_type total = transpose_reduce_sum<NI, LPR>(acc, lane);
         if (col_group < NI) {
             const int r = wave_u * RW + col_group * RPI + row_in_inst;
@@ -1198,7 +1372,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         // large solve (n = 65536: the last block streams 33 MB on its own)
         const index_type bulk_end = (block - 1 - deferred_columns) * PPB;
         if (bulk_end > swept) {
-            sweep(std::integral_constant<int, DeepDepth>{}, swept, bulk_end);
+            sweep(std::integral_constant<int, DeepDepth>{}, std::false_type{},
+                  swept, bulk_end);
             swept = bulk_end;
         }
         fold_panel();
@@ -1209,7 +1384,36 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         probe_pending = false;
     }
     if (far_end > swept) {
-        sweep(std::integral_constant<int, Depth>{}, swept, far_end);
+        // 0 = never, 1 = upper solves (default), 2 = upper and lower. Measured
+        // (profiles/r04_trsv_wide_front.txt): with the front loop AND without
+        // deferred folds an upper solve of 4-byte storage takes 273 instead of
+        // 324 us at n = 20000, 333 instead of 390 at 24000, 508 instead of 549
+        // at 32768 (equal up to 16384); the lower instantiation of the same
+        // code is 15-18 % SLOWER at 8192-16384 and equal at 24000, for reasons
+        // not found (its waits are the deeper ones in the ISA).
+#ifndef ACCBLAS_TRSV_WIDE_FRONT_LOOP
+#define ACCBLAS_TRSV_WIDE_FRONT_LOOP 1
+#endif
+        // (2-byte storage, upper: 129 -> 209 us at n = 8192 with it; its ring
+        // is three deep and its tiles half as large - not looked into)
+        if constexpr ((ACCBLAS_TRSV_WIDE_FRONT_LOOP == 2 ||
+                       (ACCBLAS_TRSV_WIDE_FRONT_LOOP == 1 && Upper &&
+                        sizeof(st_type) == 4)) &&
+                      PPB == 1) {
+            // catch up with what is published in chunks, then follow the front
+            swept = sweep(std::integral_constant<int, Depth>{}, std::true_type{},
+                          swept, far_end);
+            if (far_end > swept) {
+                if (wave_u == 0) {
+                    front_sweep(std::true_type{}, swept, far_end);
+                } else {
+                    front_sweep(std::false_type{}, swept, far_end);
+                }
+            }
+        } else {
+            sweep(std::integral_constant<int, Depth>{}, std::false_type{}, swept,
+                  far_end);
+        }
     }
     ACCBLAS_TRSV_WIDE_STAMP(2);  // this wave consumed its last far panel
     // this reduction sits between the arrival of x_{b-2} and c, i.e. on the
@@ -1473,11 +1677,12 @@ inline trsv_wide_split trsv_wide_split_for(index_type n, int num_cus,
                                blocks - last_blocks,
                                last_blocks > 0 ? ACCBLAS_TRSV_WIDE_LAST_PARTS : 1,
                                0,
-                               0};
+                               0,
+                               1};
     }
     return trsv_wide_split{blocks, 1, blocks, 1,
                            static_cast<int>(trsv_wide_deferred_columns), blocks,
-                           1, 0, 0};
+                           1, 0, 0, 1};
 }
 
 /** Tickets (units of work: row blocks, helpers' shares, prefetchers) of a
@@ -1500,7 +1705,7 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
                                   const trsv_session &session,
                                   hipStream_t stream,
                                   const trsv_wide_split &split_in,
-                                  int num_cus = 0)
+                                  int num_cus = 0, bool persistent_wanted = false)
 {
     trsv_wide_split split = split_in;
     using st_type =
@@ -1558,17 +1763,27 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
     constexpr int deep_depth = sizeof(st_type) == 2 ? 5 : 4;
     const unsigned tickets = trsv_wide_tickets(n, split);
     split.tickets = static_cast<int>(tickets);
+    // (a CU for every row block: all of them start with the solve)
+#ifndef ACCBLAS_TRSV_WIDE_ALWAYS_DEFER
+#define ACCBLAS_TRSV_WIDE_ALWAYS_DEFER 0
+#endif
+    split.defer =
+        (ACCBLAS_TRSV_WIDE_ALWAYS_DEFER == 0 && num_cus > 0 &&
+         split.parts == 1 &&
+         ceildiv(n, index_type{trsv_wide_rows}) <= index_type{num_cus})
+            ? 0
+            : 1;
     // one workgroup per ticket, but no more than one per CU: the workgroups
     // then draw tickets until none is left (`Persistent`)
     // (the persistent form of THIS kernel is only built on request,
     // -DACCBLAS_TRSV_WIDE_PERSISTENT: the loop around the row block costs it
     // 170 spilled registers, profiles/r04_trsv_persistent.txt)
 #ifdef ACCBLAS_TRSV_WIDE_PERSISTENT
-    const bool persistent =
-        num_cus > 0 && tickets > static_cast<unsigned>(num_cus);
+    const bool persistent = persistent_wanted && num_cus > 0 &&
+                            tickets > static_cast<unsigned>(num_cus);
 #else
     const bool persistent = false;
-    (void)num_cus;
+    (void)persistent_wanted;
 #endif
     const dim3 grid(persistent ? static_cast<unsigned>(num_cus) : tickets);
     const dim3 block(trsv_wide_waves * wave_size);
@@ -1644,8 +1859,8 @@ hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
                                laid_out, num_cus, prefetch_mode)
                          : 0;
     return launch_trsv_wide_split<ArType>(upper, unit_diag, mtx, x, helper,
-                                          session, stream, split,
-                                          persistent_mode != 0 ? num_cus : 0);
+                                          session, stream, split, num_cus,
+                                          persistent_mode != 0);
 }
 
 

@@ -96,7 +96,7 @@ int main(int argc, char **argv)
     struct entry { std::string name; std::function<void()> run; };
     std::vector<entry> entries = {
         {"rows64", [&]() { CHECK(launch_trsv<ar_type>(false, true, m, xv, helper, session, nullptr, 1)); }},
-        {"rows128", [&]() { CHECK(launch_trsv_wide_split<ar_type>(false, true, m, xv, helper, session, nullptr, split)); }},
+        {"rows128", [&]() { CHECK(launch_trsv_wide_split<ar_type>(false, true, m, xv, helper, session, nullptr, split, 256)); }},
     };
     hipEvent_t start, stop;
     CHECK(hipEventCreate(&start));

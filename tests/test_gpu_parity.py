@@ -314,11 +314,12 @@ def test_acc_dot_result_type_and_strides(gpu, mode):
 
 # --------------------------------------------------------------------------- TRSV
 KERNELS = {
-    # name -> (trsv_wide, trsv_relay) of accblas_set_option
-    "rows64": (0, 1),         # 64-row blocks, loader wave by the measured rule
-    "rows64_direct": (0, 0),  # every worker polls the granules it needs
-    "rows64_relay": (0, 2),   # x through the loader wave and LDS, all types/sizes
-    "rows128": (2, 1),        # 128-row blocks wherever the operands allow it
+    # name -> (trsv_wide, trsv_relay, trsv_small) of accblas_set_option
+    "rows64": (0, 1, 0),         # 64-row blocks, loader wave by the measured rule
+    "rows64_direct": (0, 0, 0),  # every worker polls the granules it needs
+    "rows64_relay": (0, 2, 0),   # x through the loader wave and LDS, all types/sizes
+    "rows128": (2, 1, 0),        # 128-row blocks wherever the operands allow it
+    "default": (1, 1, 1),        # the library's own choice (n <= 128: one workgroup)
 }
 
 
@@ -326,12 +327,14 @@ KERNELS = {
 def trsv_kernel(request, gpu):
     """Selects the TRSV kernel family for one test, restores the defaults after."""
     _, accblas = gpu
-    wide, relay = KERNELS[request.param]
+    wide, relay, small = KERNELS[request.param]
     accblas.set_option("trsv_wide", wide)
     accblas.set_option("trsv_relay", relay)
+    accblas.set_option("trsv_small", small)
     yield request.param
     accblas.set_option("trsv_wide", 1)
     accblas.set_option("trsv_relay", 1)
+    accblas.set_option("trsv_small", 1)
 
 
 _TRIANGULAR_CACHE = {}
@@ -423,7 +426,53 @@ def test_plain_trsv_equals_accessor_bitwise(gpu, trsv_kernel, vt, upper):
     assert torch.equal(x1, x2)
 
 
-@pytest.mark.parametrize("trsv_kernel", ["rows64", "rows128"], indirect=True)
+@pytest.mark.parametrize("vt", [F32, F64])
+@pytest.mark.parametrize("upper", [False, True])
+@pytest.mark.parametrize("unit", [False, True])
+@pytest.mark.parametrize("n", [1, 2, 7, 63, 64, 65, 66, 100, 127, 128])
+def test_small_systems_by_one_workgroup(gpu, vt, upper, unit, n):
+    """n <= 128 runs `kernel::trsv_small`: one workgroup, forward substitution in
+    the wave, no workspace. Any base alignment, row stride and increment; plain
+    pointers and Acc<T, T> give the same bits; the blocked kernel (the option
+    switched off) agrees within the tolerance; vector elements between the
+    increments are not touched."""
+    torch, accblas = gpu
+    lda, incx, offset = n + 3, 3, 1
+    full = triangular_system(n, lda, upper, 900 + n)
+    A = oracle.convert(np.concatenate([np.zeros(offset), full]), vt)
+    b = make_inputs(901, n, vt)
+    xb = np.full(n * incx + offset, -7.0, dtype=A.dtype)
+    xb[offset::incx][:n] = b
+    want = oracle.exact_trsv(vt, upper, unit, n, A[offset:], lda, xb[offset:], incx)
+    uplo = accblas.UPPER if upper else accblas.LOWER
+    diag = accblas.UNIT if unit else accblas.NON_UNIT
+    dA = to_dev(torch, A)
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    x_plain, x_acc, x_blocked = (to_dev(torch, xb) for _ in range(3))
+    accblas.trsv(vt, uplo, diag, n, dA[offset:], lda, x_plain[offset:], incx, helper)
+    accblas.acc_trsv(vt, vt, uplo, diag, n, dA[offset:], lda, x_acc[offset:], incx, helper)
+    accblas.set_option("trsv_small", 0)
+    try:
+        accblas.acc_trsv(vt, vt, uplo, diag, n, dA[offset:], lda, x_blocked[offset:], incx,
+                         helper)
+        torch.cuda.synchronize()
+    finally:
+        accblas.set_option("trsv_small", 1)
+    assert int(helper[0].item()) & 0xffffffff == 0xffffffff
+    assert int(helper[1].item()) == (n + 63) // 64
+    assert torch.equal(x_plain, x_acc)
+    got = x_plain.cpu().numpy()
+    tol = 100 * out_tolerance(vt, vt)
+    assert oracle.rel_error(want[::incx][:n].astype(np.float64),
+                            got[offset::incx][:n].astype(np.float64)) <= tol
+    assert oracle.rel_error(x_blocked.cpu().numpy()[offset::incx][:n].astype(np.float64),
+                            got[offset::incx][:n].astype(np.float64)) <= tol
+    untouched = np.ones(got.size, dtype=bool)
+    untouched[offset::incx][:n] = False
+    assert np.all(got[untouched] == -7.0)
+
+
+@pytest.mark.parametrize("trsv_kernel", ["rows64", "rows128", "default"], indirect=True)
 def test_trsv_manufactured_solution_strided(gpu, trsv_kernel):
     """b = T x_true formed in high precision; the solve returns x_true
     (SURVEY.md §8c C-4), with incx != 1."""
