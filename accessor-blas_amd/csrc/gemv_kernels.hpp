@@ -528,9 +528,21 @@ static_assert(gemv_short_config::wpr == gemv_short_tall_config::wpr &&
  *  of the same rows inside a larger product whichever of the two it runs. */
 using gemv_cached_config = gemv_config<8, 4, 2, 2, false>;
 constexpr index_type gemv_cached_max_bytes = index_type{320} * 1000 * 1000;
+/** The same for SHORT rows (`gemv_short_row_bytes`): the two-row short shape
+ *  without the hint, from 80 MB on (below, the non-temporal short shapes are as
+ *  fast or faster: the whole launch is a few microseconds). Same table, us,
+ *  library (short shapes, non-temporal) -> this one: Acc<fp64,fp32> n = 4500 17.7
+ *  -> 17.1, 5500 24.2 -> 22.4, 6500 32.8 -> 29.7, 7000 34.8 -> 32.3; fp64 3500
+ *  18.9 -> 18.4, 4000 23.7 -> 21.6 (rocBLAS 23.8), 4500 29.9 -> 26.4, 5000 34.2
+ *  -> 30.9. Waves per row and unroll of the short shapes: the same bits. */
+using gemv_short_cached_config = gemv_config<4, 2, 2, 2, false>;
+constexpr index_type gemv_cached_min_bytes = index_type{80} * 1000 * 1000;
 static_assert(gemv_cached_config::wpr == gemv_default_config::wpr &&
                   gemv_cached_config::unroll == gemv_default_config::unroll,
               "the cached shape must sum a row in the production shape's order");
+static_assert(gemv_short_cached_config::wpr == gemv_short_config::wpr &&
+                  gemv_short_cached_config::unroll == gemv_short_config::unroll,
+              "the cached short shape must sum a row in the short shapes' order");
 
 /** When the time-skewed sweep is used (option "gemv_skew" of the C ABI). */
 enum class gemv_skew_mode {
@@ -636,9 +648,22 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
                 } else if (std::is_same<Config, gemv_default_config>::value &&
                            cols * static_cast<index_type>(sizeof(st_type)) <=
                                gemv_short_row_bytes<st_type>) {
-                    // short rows (the choice between the two shapes does not
+                    // short rows (the choice between the shapes does not
                     // change the bits of a row, see gemv_short_config)
-                    if (rows <= gemv_short_max_rows) {
+                    const index_type matrix_bytes =
+                        rows * cols * static_cast<index_type>(sizeof(st_type));
+                    if (matrix_bytes >= gemv_cached_min_bytes &&
+                        matrix_bytes <= gemv_cached_max_bytes) {
+                        // fits the Infinity Cache and is large enough for that
+                        // to matter: the two-row shape with the default cache
+                        // policy (see gemv_cached_config)
+                        using shape = gemv_short_cached_config;
+                        kernel::gemv_vec<shape, vec16, true, false, false>
+                            <<<dim3(static_cast<unsigned>(
+                                   ceildiv(rows, shape::rows_per_block))),
+                               dim3(shape::waves * wave_size), 0, stream>>>(
+                                alpha, mtx, x, beta, res);
+                    } else if (rows <= gemv_short_max_rows) {
                         using shape = gemv_short_config;
                         kernel::gemv_vec<shape, vec16, true, false, false>
                             <<<dim3(static_cast<unsigned>(

@@ -840,7 +840,9 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     // 200-590 bytes of scratch instead of 78-129 registers)
     int lane_now = lane_of_thread;
     int wave_now = wave_of_thread;
-    asm volatile("" : "+v"(lane_now), "+v"(wave_now));
+    if constexpr (persistent) {
+        asm volatile("" : "+v"(lane_now), "+v"(wave_now));
+    }
     const int lane = lane_now;
     const int wave = wave_now;
 #ifdef ACCBLAS_TRSV_DIAG
@@ -912,12 +914,16 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     st_type *own_addr = x_data + phys(inside(own_row)) * x_inc;
     // (kept in LDS, not in a register of every wave, until the far sweep is
     // over: the far sweep needs the registers)
-    // (the load goes out ahead of the tile's, the value is parked in LDS
-    // behind them: one memory latency for all)
+    // (persistent: the load goes out ahead of the tile's, the value is parked
+    // in LDS behind them - the loop around the row block needs the registers;
+    // one block per workgroup: every wave keeps it in a register, 1 us faster
+    // per solve at n = 200 ... 2000)
     st_type own_raw{};
-    if (wave == 0) {
+    if (!persistent || wave == 0) {
         own_raw = *own_addr;  // (clamped address: unconditional)
     }
+    const ar_type own_rhs =
+        own_valid ? static_cast<ar_type>(own_raw) : ar_type{};
 
     // ---- diagonal tile and last panel -> LDS (a wave reads one row) -------
     // Every load of the wave's rows is issued before the first use, so the
@@ -962,8 +968,8 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
             }
         }
     }
-    if (wave == 0) {
-        own_lds[lane] = own_valid ? static_cast<ar_type>(own_raw) : ar_type{};
+    if (persistent && wave == 0) {
+        own_lds[lane] = own_rhs;
     }
     __syncthreads();
 
@@ -1358,7 +1364,9 @@ __global__ __launch_bounds__((Waves + (Relay ? 1 : 0)) * wave_size) void trsv(
     if (wave == 0) {
         ACCBLAS_TRSV_STAMP(block, 3);  // all waves finished the far sweep
     }
-    ar_type rhs = own_valid ? own_lds[lane] - correction[lane] : ar_type{};
+    ar_type rhs =
+        own_valid ? (persistent ? own_lds[lane] : own_rhs) - correction[lane]
+                  : ar_type{};
     if (worker) {
         // every wave holds the full right-hand side (lane = row); entry
         // wave*CW + j of it multiplies column wave*CW + j of the inverse

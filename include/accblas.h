@@ -83,17 +83,22 @@ size_t accblas_dtype_size(accblas_dtype t);
 /* Tuning knobs (no counterpart in the reference, whose choices are
  * compile-time constants). The knobs take 0, 1 or 2 unless said otherwise.
  * Known names:
- *   "trsv_wide"   1 (default) = systems with n >= 4096 (8-byte storage:
- *                 4096 <= n < 17000 or n > 32768) and a 16-byte aligned
- *                 matrix base and row stride use 128-row blocks
- *                 (`kernel::trsv_wide`: half as many dependent hops through
- *                 memory, the folded panel held in registers), everything
- *                 else 64-row blocks (`kernel::trsv`); 0 = 64-row blocks only;
- *                 2 = 128-row blocks whenever the operands allow it.
+ *   "trsv_wide"   1 (default) = systems of 2- or 4-byte storage with
+ *                 n >= 4096 and a 16-byte aligned matrix base and row stride use
+ *                 128-row blocks (`kernel::trsv_wide`: half as many dependent
+ *                 hops through memory, the folded panel held in registers),
+ *                 everything else - 8-byte storage at every size - 64-row blocks
+ *                 (`kernel::trsv`); 0 = 64-row blocks only; 2 = 128-row blocks
+ *                 whenever the operands allow it.
  *   "trsv_relay"  64-row kernel only: 1 (default) = the far sweep's x goes
  *                 through a loader wave and LDS where that was measured to pay
- *                 (fp16 storage, fp32 arithmetic, fp64 storage from n = 17000);
+ *                 (fp16 storage, fp32 arithmetic; fp64 arithmetic from n = 1024
+ *                 with 8-byte and from n = 2048 with 4-byte storage);
  *                 0 = never; 2 = always.
+ *   "trsv_small"  1 (default) = systems of at most 128 unknowns are solved by
+ *                 one workgroup without a workspace (`kernel::trsv_small`:
+ *                 forward substitution in the wave; any alignment, row stride
+ *                 and increment); 0 = the blocked kernels at every size.
  *   "gemv_skew"   1 (default) = GEMV with fp64 arithmetic and a power-of-two
  *                 row pitch (>= 16 KiB) uses the time-skewed sweep (rows of
  *                 a group walk the columns one chunk apart, against channel

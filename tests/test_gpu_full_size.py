@@ -396,3 +396,51 @@ def test_trsv_loader_wave_variant_residuals(gpu, ar, st, n, tol, upper):
     resid = Tr @ x.double() + x.double()[rows] - b.double()[rows]
     rel = float(resid.abs().sum() / b.double()[rows].abs().sum())
     assert rel <= tol, rel
+
+
+@pytest.mark.parametrize("vt", [F32, F64])
+def test_trsv_accessor_costs_nothing_over_plain_pointers(gpu, vt):
+    """The reference's premise, timed: `acc_trsv<T, T>` takes as long as
+    `trsv<T>` (its tables list both, `/root/reference/cuda/trsv_benchmark.cu:126-160`).
+    The CLI's default problem - upper / unit, n = 24000 inside a 24000-wide matrix -,
+    the two alternated solve by solve on the same buffers, minimum of 10 each
+    (`benchmark_function`'s protocol): within 3 %. In round 3 the fp64 pair differed
+    by up to 17 %: identical instruction streams, but late row blocks that did or
+    did not catch up in time (profiles/r04_trsv_plain_vs_acc.txt)."""
+    torch, accblas = gpu
+    n = lda = 24000
+    tdt = accblas.torch_dtype(vt)
+    A = uniform(torch, n * lda, torch.float32, 71, scale=1.0 / n ** 0.5).to(tdt)
+    x0 = uniform(torch, n, torch.float32, 72).to(tdt)
+    x = x0.clone()
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+
+    def plain():
+        accblas.trsv(vt, accblas.UPPER, accblas.UNIT, n, A, lda, x, 1, helper)
+
+    def acc():
+        accblas.acc_trsv(vt, vt, accblas.UPPER, accblas.UNIT, n, A, lda, x, 1, helper)
+
+    def timed(fn):
+        x.copy_(x0)
+        torch.cuda.synchronize()
+        a, b = accblas.Event(), accblas.Event()
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_ms(b) * 1e3
+
+    for fn in (plain, acc):  # warm-up
+        timed(fn)
+    bits = {}
+    times = {"plain": [], "acc": []}
+    for _ in range(10):
+        for name, fn in (("plain", plain), ("acc", acc)):
+            times[name].append(timed(fn))
+            bits.setdefault(name, x.clone())
+            assert torch.equal(bits[name], x)
+    assert not accblas.trsv_status(helper)
+    assert torch.equal(bits["plain"], bits["acc"])
+    ratio = min(times["acc"]) / min(times["plain"])
+    assert abs(ratio - 1.0) <= 0.03, (ratio, times)
