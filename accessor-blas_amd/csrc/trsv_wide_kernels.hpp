@@ -1180,19 +1180,32 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             x_chunk[H + lane] = io::decode(probe1);
             // this wave's share of the tile `Depth - 1` columns ahead, into
             // the slot of the column consumed one step ago
-            if (c >= 1 && c - 1 + Depth < far_end) {
+#ifndef ACCBLAS_TRSV_WIDE_DEFERRED_REFILL
+#define ACCBLAS_TRSV_WIDE_DEFERRED_REFILL 1
+#endif
+            if (ACCBLAS_TRSV_WIDE_DEFERRED_REFILL != 0 && c >= 1 &&
+                c - 1 + Depth < far_end) {
                 issue(c - 1 + Depth, previous);
             }
         }
         lds_barrier();
         apply(c, slot, col_group * Vec);
+#ifndef ACCBLAS_TRSV_WIDE_TOUCH
+#define ACCBLAS_TRSV_WIDE_TOUCH 1
+#endif
         if constexpr (Poller) {
             if (c + 1 < far_end) {
                 poll_begin((c + 1) * R + lane, probe0, probe1);
                 probe_pending = true;
             }
+            if (ACCBLAS_TRSV_WIDE_DEFERRED_REFILL == 0 && refill) {
+                // (experiment: the poller refills like everybody else, behind
+                // its early probe)
+                issue(c + Depth, slot);
+            }
         } else {
-            if (wave_u == 1 && c + Depth < far_end) {
+            if (ACCBLAS_TRSV_WIDE_TOUCH != 0 && wave_u == 1 &&
+                c + Depth < far_end) {
                 // wave 0's rows of the tile it will ask for one hop from now:
                 // one 4-byte load per 128-byte line (default cache policy)
                 constexpr int line_elements = 128 / static_cast<int>(sizeof(st_type));
@@ -1230,7 +1243,9 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         for (int d = 0; d < D; ++d) {
             // (the poller's share of step begin + D - 1 is requested by its
             // first step, as of every later one)
-            if (begin + d < end && !(Poller && d == D - 1 && begin >= 1)) {
+            if (begin + d < end &&
+                !(ACCBLAS_TRSV_WIDE_DEFERRED_REFILL != 0 && Poller &&
+                  d == D - 1 && begin >= 1)) {
                 issue(begin + d, ring[d]);
             }
         }

@@ -14,10 +14,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PACKAGE_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))
-# (ACCBLAS_LIB_PATH: another build of the same library, for A/B measurements
-# of kernel variants inside one gpurun call; never a different implementation)
-LIB_PATH = os.environ.get("ACCBLAS_LIB_PATH") or \
-    os.path.join(PACKAGE_ROOT, "lib", "libaccblas_hip.so")
+# The in-tree build, always. (The developer probes under tools/ that compare
+# builds set `accblas.LIB_PATH` themselves before `load()`; no environment
+# variable redirects this binding - bench.py and the tests measure lib/.)
+LIB_PATH = os.path.join(PACKAGE_ROOT, "lib", "libaccblas_hip.so")
 
 F16, F32, F64 = 0, 1, 2
 UPPER, LOWER = 0, 1
@@ -123,6 +123,14 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def library_identity():
+    """(path, sha256) of the shared library this binding loads: bench.py records
+    it beside its numbers."""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        return LIB_PATH, hashlib.sha256(f.read()).hexdigest()
 
 
 def _check(status):

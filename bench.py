@@ -879,6 +879,13 @@ def main():
             res_cpu.astype(np.float64), got_h[:sample_rows].astype(np.float64))
     if extras is not None:
         out["other_configs"] = extras
+    # which binary these numbers belong to
+    lib_path, lib_sha = accblas.library_identity()
+    out["library"] = {"path": os.path.relpath(lib_path, REPO), "sha256": lib_sha}
+    hash_file = os.path.join(os.path.dirname(lib_path), "SOURCE_HASH")
+    if os.path.exists(hash_file):
+        with open(hash_file) as f:
+            out["library"]["source_hash"] = f.read().strip()
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

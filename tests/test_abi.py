@@ -175,3 +175,19 @@ def test_shard_bounds_properties():
             assert all(p[1] % align == 0 for p in pieces[:-1])
 
     check()
+
+
+def test_no_environment_variable_redirects_the_binding(monkeypatch):
+    """bench.py and the parity tests measure the in-tree build: ACCBLAS_LIB_PATH
+    (honoured until round 3) must not point the binding anywhere else. The
+    developer probes that compare builds set `accblas.LIB_PATH` themselves."""
+    import importlib
+    monkeypatch.setenv("ACCBLAS_LIB_PATH", "/nonexistent/libaccblas_hip.so")
+    fresh = importlib.reload(accblas)
+    try:
+        assert fresh.LIB_PATH == os.path.join(fresh.PACKAGE_ROOT, "lib", "libaccblas_hip.so")
+        path, sha = fresh.library_identity()
+        assert path == fresh.LIB_PATH and len(sha) == 64
+    finally:
+        monkeypatch.delenv("ACCBLAS_LIB_PATH")
+        importlib.reload(accblas)

@@ -70,6 +70,27 @@ def main():
         json.dump({"source": f"profiles/{tag}_gemv_pmc.json",
                    "gemv_vec_bytes_per_launch": read_bytes + write_bytes,
                    "gemv_kernels_sha256": kernel_source_hash()}, f, indent=1)
+    # One kernel name can cover launches of different shapes (the headline GEMV
+    # and the row block one GPU of eight would own run the same instantiation):
+    # the trace grouped by kernel AND grid, so that every entry of the bench's
+    # `other_configs` can be looked up on its own
+    trace = os.path.join(OUT, "prof_stats", "gemv_kernel_trace.csv")
+    if os.path.exists(trace):
+        groups = defaultdict(list)
+        for r in csv.DictReader(open(trace)):
+            name = r["Kernel_Name"]
+            if "accblas" not in name:
+                continue
+            key = (name, int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]))
+            groups[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        with open(os.path.join(PROF, f"{tag}_gemv_kernel_stats_by_grid.csv"), "w") as f:
+            out = csv.writer(f)
+            out.writerow(["Name", "Grid_Size_X", "Workgroup_Size_X", "Calls", "AverageNs",
+                          "MinNs", "MaxNs"])
+            for (name, grid, block), ns in sorted(groups.items(),
+                                                  key=lambda kv: -sum(kv[1])):
+                out.writerow([name, grid, block, len(ns), f"{sum(ns) / len(ns):.1f}", min(ns),
+                              max(ns)])
     for name in ("dot", "trsv"):
         src = os.path.join(OUT, f"prof_{name}", f"{name}_kernel_stats.csv")
         if os.path.exists(src):
