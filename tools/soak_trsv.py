@@ -15,9 +15,11 @@ import accblas  # noqa: E402
 F16, F32, F64 = accblas.F16, accblas.F32, accblas.F64
 
 
-def main(iterations=4000, seed=7):
+def main(iterations=4000, seed=7, max_n=14000):
+    # (14000: 110 row blocks of 128, the split blocks can be exercised; from
+    # ~17000 on the 64-row kernel has more row blocks than CUs and its workgroups
+    # draw tickets until none is left: second argument)
     rng = np.random.default_rng(seed)
-    max_n = 14000  # 110 row blocks of 128: the split blocks can be exercised
     scale = 1.0 / np.sqrt(max_n)
     base = (torch.rand(max_n * max_n, dtype=torch.float64, device="cuda") * 2 - 1) * scale
     mats = {F64: base, F32: base.float(), F16: base.half()}
@@ -64,4 +66,5 @@ def main(iterations=4000, seed=7):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 4000)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 4000,
+         max_n=int(sys.argv[2]) if len(sys.argv) > 2 else 14000)

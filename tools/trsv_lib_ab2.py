@@ -18,6 +18,7 @@ import torch
 REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 ST = {"f16": (0, torch.float16), "f32": (1, torch.float32), "f64": (2, torch.float64)}
 F64, UNIT = 2, 1
+AR = {"f32": 1, "f64": 2}[os.environ.get("AR", "f64")]  # arithmetic type (AR=f32 in the environment)
 UPLO = 0 if os.environ.get("UPLO", "lower") == "upper" else 1  # accblas_uplo
 
 st_name, reps = sys.argv[1], int(sys.argv[2])
@@ -38,7 +39,7 @@ for name in names:
     lib.accblas_acc_trsv.argtypes = [ctypes.c_int] * 4 + [i64, vp, i64, vp, i64, vp, vp]
     libs.append(lib)
 helper = torch.zeros(2, dtype=torch.int32, device="cuda")
-print(f"st={st_name} {'upper' if UPLO == 0 else 'lower'} reps={reps}; per build: min / median us", flush=True)
+print(f"st={st_name} ar={os.environ.get('AR', 'f64')} {'upper' if UPLO == 0 else 'lower'} reps={reps}; per build: min / median us", flush=True)
 for n in sizes:
     scale = 1.0 / n ** 0.5
     lda = max(n, int(os.environ.get("LDA", "0")))  # (LDA in the environment: row stride, as the CLIs' sweeps have it)
@@ -56,7 +57,7 @@ for n in sizes:
 
     def solve(lib):
         x.copy_(x0)
-        rc = lib.accblas_acc_trsv(F64, st, UPLO, UNIT, n, A.data_ptr(), lda, x.data_ptr(), 1,
+        rc = lib.accblas_acc_trsv(AR, st, UPLO, UNIT, n, A.data_ptr(), lda, x.data_ptr(), 1,
                                   helper.data_ptr(), None)
         assert rc == 0, rc
     t_copy = min(timed(lambda: x.copy_(x0)) for _ in range(8))
