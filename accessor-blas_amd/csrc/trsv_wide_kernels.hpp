@@ -85,11 +85,12 @@ struct trsv_wide_split {
     // `trsv_wide_grid` returns. A launch may have fewer workgroups than
     // tickets (one per CU): they draw tickets until none is left.
     int tickets;
-    // Do row blocks with a long far sweep fold their panel late (see
-    // `defer_fold` in the kernel)? Only where row blocks start late: with a
-    // CU for every row block (set by the launcher) all of them start with the
-    // solve and fold at once, while the chain is still far away.
-    int defer;
+    // Row blocks from this one on fold their panel late when their far sweep
+    // is long (see `defer_fold` in the kernel): the row blocks that START late.
+    // The ones that have a CU from the first moment of the solve (set by the
+    // launcher: all of them, or the first `num_cus`) fold at once, while the
+    // chain is still far away.
+    int defer_from;
 };
 constexpr int trsv_wide_max_parts = trsv_partial_slots + 1;
 // helpers' sums an owner takes through LDS at a time
@@ -795,14 +796,18 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     };
     // block columns that are swept after W has been computed when W is
     // deferred (W takes ~10 us; the chain's front must still be far away)
-    // With every row block resident from the start (split.defer == 0) nothing
-    // is deferred: the block would follow the front through its bulk columns,
+    // A row block that is resident from the start (block < split.defer_from)
+    // defers nothing: it would follow the front through its bulk columns,
     // fall 7-8 columns behind while it folds (~14 us), and catch up at one tile
     // per memory latency - the pace of the chain itself - so the chain ends up
     // waiting for it (16 us at block 97 of 188, n = 24000, 5 us at every ~10th
     // block behind it: profiles/r04_trsv_wide_front.txt).
+    // (a split block always defers: its helpers' sums are joined where it
+    // folds)
     const bool defer_fold =
-        split.defer != 0 && block - 1 >= 2 * trsv_wide_deferred_columns;
+        (block >= split.defer_from ||
+         (split.parts > 1 && block >= split.first_block)) &&
+        block - 1 >= 2 * trsv_wide_deferred_columns;
     // (the owners of the last blocks start when the front has already passed
     // most of what they would keep, and sweep it with the shallow ring)
     const index_type deferred_columns =
@@ -1693,11 +1698,11 @@ inline trsv_wide_split trsv_wide_split_for(index_type n, int num_cus,
                                last_blocks > 0 ? ACCBLAS_TRSV_WIDE_LAST_PARTS : 1,
                                0,
                                0,
-                               1};
+                               0};
     }
     return trsv_wide_split{blocks, 1, blocks, 1,
                            static_cast<int>(trsv_wide_deferred_columns), blocks,
-                           1, 0, 0, 1};
+                           1, 0, 0, 0};
 }
 
 /** Tickets (units of work: row blocks, helpers' shares, prefetchers) of a
@@ -1779,17 +1784,13 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
     const unsigned tickets = trsv_wide_tickets(n, split);
     split.tickets = static_cast<int>(tickets);
     // (a CU for every row block: all of them start with the solve)
+    // (row blocks below the CU count start with the solve; ALWAYS_DEFER = 1:
+    // round 3's rule, every long sweep defers)
 #ifndef ACCBLAS_TRSV_WIDE_ALWAYS_DEFER
 #define ACCBLAS_TRSV_WIDE_ALWAYS_DEFER 0
 #endif
-    split.defer =
-        (ACCBLAS_TRSV_WIDE_ALWAYS_DEFER == 0 && num_cus > 0 &&
-         split.parts == 1 &&
-         ceildiv(n, index_type{trsv_wide_rows}) <= index_type{num_cus})
-            ? 0
-            : 1;
-    // one workgroup per ticket, but no more than one per CU: the workgroups
-    // then draw tickets until none is left (`Persistent`)
+    split.defer_from =
+        (ACCBLAS_TRSV_WIDE_ALWAYS_DEFER == 0 && num_cus > 0) ? num_cus : 0;
     // (the persistent form of THIS kernel is only built on request,
     // -DACCBLAS_TRSV_WIDE_PERSISTENT: the loop around the row block costs it
     // 170 spilled registers, profiles/r04_trsv_persistent.txt)
