@@ -540,6 +540,49 @@ __device__ __forceinline__ typename mma_16x16x4<T>::acc_type mma_tile_product(
 
 
 /**
+ * Forward substitution with a 64 x 64 lower-triangular tile by ONE wave: lane i
+ * owns row i and its running right-hand side `r`, the solved x_j goes from lane
+ * j to all lanes through SGPRs (`v_readlane`), one fused multiply-add per step
+ * and lane; a row's coefficients come from LDS sixteen columns ahead. ~35
+ * cycles per unknown - against 16 serial steps, two levels of matrix-core
+ * products and four barriers for an inverse, which pays only where a block
+ * waits for its turn with the inverse in hand.
+ * T[i][j] = tile[i * row_stride + j * col_stride]; entries on and above the
+ * diagonal are not read. `inv_diag` = 1 / T[i][i] (1 for a unit diagonal).
+ * Rows from `rows` on do not exist. Returns x_i in lane i:
+ * x_i = (r_i - sum_{j < i} T[i][j] x_j) * inv_diag_i, the sum in ascending j.
+ */
+template <bool UnitDiag, typename T>
+__device__ __forceinline__ T substitute_tile64(const T *tile, int row_stride,
+                                               int col_stride, T r, T inv_diag,
+                                               int lane, int rows)
+{
+    constexpr int chunk = 16;
+#pragma unroll
+    for (int j0 = 0; j0 < trsv_tile; j0 += chunk) {
+        if (j0 < rows) {  // (wave-uniform)
+            // this lane's coefficients of columns j0 .. j0 + 15: all LDS reads
+            // of the chunk are issued before its first dependent step
+            T a[chunk];
+#pragma unroll
+            for (int q = 0; q < chunk; ++q) {
+                const T value =
+                    tile[lane * row_stride + (j0 + q) * col_stride];
+                a[q] = lane > j0 + q ? value : T{};
+            }
+#pragma unroll
+            for (int q = 0; q < chunk; ++q) {
+                const T mine = UnitDiag ? r : r * inv_diag;
+                const T xj = read_lane(mine, j0 + q);
+                r -= a[q] * xj;
+            }
+        }
+    }
+    return UnitDiag ? r : r * inv_diag;
+}
+
+
+/**
  * In-place inverse of a 64 x 64 lower-triangular tile in LDS by a team of (at
  * least) four waves; every thread of the team must call it (it contains team
  * barriers = __syncthreads(): all teams of the workgroup call it together).

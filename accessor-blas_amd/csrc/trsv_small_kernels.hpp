@@ -40,46 +40,6 @@ constexpr index_type trsv_small_max_n = 128;
 
 
 namespace kernel {
-namespace detail {
-
-
-/**
- * Forward substitution with a 64 x 64 lower-triangular tile by one wave.
- * `tile` = the tile column-major with leading dimension `ld`
- * (tile[j * ld + i] = T[i][j]); entries on and above the diagonal are not read.
- * Lane i holds `r` = its right-hand side and `inv_diag` = 1 / T[i][i] (1 for a
- * unit diagonal). Rows from `rows` on do not exist. Returns x_i in lane i.
- * x_i = (r_i - sum_{j < i} T[i][j] x_j) * inv_diag_i, the sum in ascending j.
- */
-template <bool UnitDiag, typename T>
-__device__ __forceinline__ T substitute_tile64(const T *tile, int ld, T r,
-                                               T inv_diag, int lane, int rows)
-{
-    constexpr int chunk = 16;
-#pragma unroll
-    for (int j0 = 0; j0 < trsv_tile; j0 += chunk) {
-        if (j0 < rows) {  // (wave-uniform)
-            // this lane's coefficients of columns j0 .. j0 + 15: all LDS reads
-            // of the chunk are issued before its first dependent step
-            T a[chunk];
-#pragma unroll
-            for (int q = 0; q < chunk; ++q) {
-                const T value = tile[(j0 + q) * ld + lane];
-                a[q] = lane > j0 + q ? value : T{};
-            }
-#pragma unroll
-            for (int q = 0; q < chunk; ++q) {
-                const T mine = UnitDiag ? r : r * inv_diag;
-                const T xj = ::accblas::dev::kernel::detail::read_lane(mine, j0 + q);
-                r -= a[q] * xj;
-            }
-        }
-    }
-    return UnitDiag ? r : r * inv_diag;
-}
-
-
-}  // namespace detail
 
 
 /**
@@ -196,7 +156,7 @@ __global__ __launch_bounds__(256) void trsv_small(MtxView mtx, XView x,
     const int rows0 = n < B ? static_cast<int>(n) : B;
     const ar_type r0 = lane < n ? static_cast<ar_type>(rhs_raw[0]) : ar_type{};
     const ar_type x0 = detail::substitute_tile64<UnitDiag>(
-        tiles[0], ld, r0, inv_diag[0], lane, rows0);
+        tiles[0], 1, ld, r0, inv_diag[0], lane, rows0);
     const st_type x0_stored = static_cast<st_type>(x0);
     if (lane < n) {
         x_data[phys(lane) * x_inc] = x0_stored;
@@ -221,7 +181,7 @@ __global__ __launch_bounds__(256) void trsv_small(MtxView mtx, XView x,
                            ((part[0] + part[1]) + (part[2] + part[3]))
                      : ar_type{};
     const ar_type x1 = detail::substitute_tile64<UnitDiag>(
-        tiles[1], ld, r1, inv_diag[1], lane, static_cast<int>(n) - B);
+        tiles[1], 1, ld, r1, inv_diag[1], lane, static_cast<int>(n) - B);
     if (B + lane < n) {
         x_data[phys(B + lane) * x_inc] = static_cast<st_type>(x1);
     }

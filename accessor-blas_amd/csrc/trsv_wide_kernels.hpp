@@ -656,10 +656,24 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     __syncthreads();
     ACCBLAS_TRSV_WIDE_STAMP(13);  // tiles staged
 
+    // EXPERIMENT, off (ACCBLAS_TRSV_WIDE_DIRECT = number of such blocks): the
+    // first row blocks do not invert - they keep the staged triangle and solve
+    // by substitution at their turn (see "direct row blocks" below). Block 0
+    // then publishes 9.6 us after the launch instead of 14.9 (n = 8192), but a
+    // direct hop takes 5 us (two 64-row substitutions + a mat-vec by one wave)
+    // against 2.4 us with the inverse, and the first block with a FOLDED panel
+    // publishes at 35-36 us either way: all folds finish 24 us after the launch
+    // (12 us of matrix-core time per block) and the block then has its far
+    // columns to catch up on. Same solve times (profiles/r04_trsv_wide_start.txt).
+#ifndef ACCBLAS_TRSV_WIDE_DIRECT
+#define ACCBLAS_TRSV_WIDE_DIRECT 0
+#endif
+    constexpr index_type direct_blocks = ACCBLAS_TRSV_WIDE_DIRECT;
+    const bool direct_block = block < direct_blocks;
     // ---- invert D00 (even waves) and D11 (odd waves) at the same time -------
     // (the serial 16 x 16 substitutions run on team wave 0 = waves 0 and 1,
     // which sit on different SIMDs)
-    if (!helper_part) {
+    if (!helper_part && !direct_block) {
         const int team = wave_u % 2;
         ar_type *scratch = tiles[3] + team * 1024;
         detail::invert_tile64<UnitDiag>(tiles[team], scratch, scratch + 512,
@@ -670,7 +684,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     ACCBLAS_TRSV_WIDE_STAMP(14);  // diagonal tiles inverted
 
     // ---- X10 = -X11 (D10 X00): 16 output tiles, two per wave ---------------
-    if (!helper_part) {
+    if (!helper_part && !direct_block) {
         const int tj = wave_u % 4;
         const int ti_of[2] = {wave_u / 4, 3 - wave_u / 4};
         typename mma::acc_type y[2];
@@ -814,13 +828,20 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         (split.parts > 1 && block >= split.tail_block)
             ? index_type{split.tail_deferred}
             : trsv_wide_deferred_columns;
-    // The first few blocks are due before a fold (~14 us) could finish: they
-    // treat x_{b-1} as one more far column (a reduction and the c mat-vec on
-    // their hop, ~0.6 us more) and start the chain ~15 us earlier.
+    // The first few blocks are due before a fold could finish: they treat
+    // x_{b-1} as one more far column (a reduction and the c mat-vec on their
+    // hop, 2.4 us instead of 1.7) and start the chain ~15 us earlier. Every
+    // block's fold is done 24 us after the launch (slowest wave; the inverse at
+    // 12), block 0 publishes at 15 us: with six such blocks (rounds 2-3) the
+    // chain stood still from 26.6 to 35 us, when block 6 had folded AND caught
+    // up on its far columns; eight: -1...-6 % at n = 4096 ... 8192, -1...-2 % at
+    // 24000, eleven and fourteen no better (profiles/r04_trsv_wide_start.txt).
 #ifndef ACCBLAS_TRSV_WIDE_UNFOLDED
-#define ACCBLAS_TRSV_WIDE_UNFOLDED 6
+#define ACCBLAS_TRSV_WIDE_UNFOLDED 8
 #endif
     constexpr index_type unfolded_blocks = ACCBLAS_TRSV_WIDE_UNFOLDED;
+    static_assert(direct_blocks <= unfolded_blocks,
+                  "a direct row block treats x_{b-1} as a far column");
     const bool folded = block >= unfolded_blocks;
     if (folded && !defer_fold && !helper_part) {
         fold_panel();
@@ -1451,6 +1472,57 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     lds_barrier();  // (what is handed over lives in LDS)
     ACCBLAS_TRSV_WIDE_STAMP(4);  // every wave's far sums in LDS
 
+    if (direct_block) {
+        // ---- direct row blocks: substitution instead of an inverse ----------
+        // rhs_lds holds this block's right-hand side minus ALL earlier columns
+        // (x_{b-1} was swept like any far column). Wave 0 alone, no barrier:
+        // x_top = T00 \ rhs_top in the wave (lane = row), r = rhs_bottom -
+        // T10 x_top (lane = row, x_top broadcast from LDS), x_bottom = T11 \ r.
+        // The triangle lies in LDS as staged: row-major, zeros above the
+        // diagonal, identity rows where the matrix ends.
+        if (wave_u == 0) {
+            const ar_type *t00 = tiles[0], *t11 = tiles[1], *t10 = tiles[2];
+            ar_type inv_top{1}, inv_bottom{1};
+            if (!UnitDiag) {
+                inv_top = ar_type{1} / t00[lane * ld + lane];
+                inv_bottom = ar_type{1} / t11[lane * ld + lane];
+            }
+            const index_type left = n - base;  // rows of the block that exist
+            const int rows_top = left < H ? static_cast<int>(left) : H;
+            const int rows_bottom =
+                left <= H ? 0 : (left - H < H ? static_cast<int>(left - H) : H);
+            const ar_type x_top = detail::substitute_tile64<UnitDiag>(
+                t00, ld, 1, rhs_lds[lane], inv_top, lane, rows_top);
+            own_lds[lane] = x_top;  // (own_lds went into rhs_lds: free)
+            lds_release();
+            lds_acquire();
+            ar_type part[4] = {};
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                part[j & 3] += t10[lane * ld + j] * own_lds[j];
+            }
+            const ar_type r_bottom =
+                rhs_lds[H + lane] - ((part[0] + part[1]) + (part[2] + part[3]));
+            ACCBLAS_TRSV_WIDE_STAMP(5);
+            const ar_type x_bottom = detail::substitute_tile64<UnitDiag>(
+                t11, ld, 1, r_bottom, inv_bottom, lane, rows_bottom);
+            const ar_type halves[2] = {x_top, x_bottom};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const index_type own_row = base + h * H + lane;
+                if (own_row < n) {
+                    // (virtual unknowns of an upper solve: handed on - x = 0
+                    // -, not stored)
+                    const st_type solution = static_cast<st_type>(halves[h]);
+                    io::publish(granules, own_row, solution, epoch);
+                    if (own_row >= pad) {
+                        x_data[phys(own_row) * x_inc] = solution;
+                    }
+                }
+            }
+            ACCBLAS_TRSV_WIDE_STAMP(9);  // published
+        }
+    } else {
     // the poller's first probe for x_{b-1} travels while c is computed
     granule_word tail_raw0[io::words];
     granule_word tail_raw1[io::words];
@@ -1549,6 +1621,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         }
     }
     ACCBLAS_TRSV_WIDE_STAMP(9);  // published
+    }  // block with an inverse
     }  // owner
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
     if (lane == 0 && trsv_wide_diag_buffer != nullptr && !helper_part) {
