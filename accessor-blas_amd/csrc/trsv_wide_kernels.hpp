@@ -943,12 +943,16 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     struct stage {
         st_type a[NI][Vec];
     };
-    const st_type *row_ptr[NI];
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        const index_type gr = base + wave_u * RW + k * RPI + row_in_inst;
-        row_ptr[k] = a_data + phys(inside(gr)) * lda;
-    }
+    // (the NI row pointers of a step are formed where they are used, one
+    // multiply-add each: as an array they are 16 registers that live through
+    // every sweep, and what the compiler spilled to make room for them was
+    // reloaded - behind the tile requests in flight - on the block's two-hop
+    // path: 0.7 us per hop in the lower instantiation of the front loop,
+    // profiles/r04_trsv_wide_front.txt)
+    const index_type sweep_row0 = base + wave_u * RW + row_in_inst;
+    const auto row_ptr = [&](int k) {
+        return a_data + phys(inside(sweep_row0 + k * RPI)) * lda;
+    };
     // (upper: first logical column from which whole vectors exist)
     const index_type first_real_vector = ceildiv(pad, index_type{Vec}) * Vec;
     const auto issue = [&](index_type cb, stage &s) {
@@ -965,7 +969,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                   : first_col;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
-            const auto v = load_packed<Vec, ACCBLAS_TRSV_NT>(row_ptr[k] + mem_col);
+            const auto v = load_packed<Vec, ACCBLAS_TRSV_NT>(row_ptr(k) + mem_col);
 #pragma unroll
             for (int e = 0; e < Vec; ++e) {
                 s.a[k][e] = v[e];
@@ -1425,20 +1429,24 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         probe_pending = false;
     }
     if (far_end > swept) {
-        // 0 = never, 1 = upper solves (default), 2 = upper and lower. Measured
-        // (profiles/r04_trsv_wide_front.txt): with the front loop AND without
-        // deferred folds an upper solve of 4-byte storage takes 273 instead of
-        // 324 us at n = 20000, 333 instead of 390 at 24000, 508 instead of 549
-        // at 32768 (equal up to 16384); the lower instantiation of the same
-        // code is 15-18 % SLOWER at 8192-16384 and equal at 24000, for reasons
-        // not found (its waits are the deeper ones in the ISA).
+        // 0 = never, 1 = 4-byte storage (default), 2 = every storage type.
+        // Measured (profiles/r04_trsv_wide_front.txt): with the front loop AND
+        // without deferred folds an upper solve of 4-byte storage takes 273
+        // instead of 324 us at n = 20000, 333 instead of 390 at 24000, 508
+        // instead of 549 at 32768 (equal up to 16384). The lower instantiation
+        // gained nothing and lost 15-18 % at 8192-16384 as long as it spilled
+        // (60 bytes of row addresses, reloaded on the two-hop path behind the
+        // tile loads in flight); with the addresses formed where they are used
+        // (`row_ptr`) it is equal up to 16384 and takes 333 instead of 382 us
+        // at 24000, 505 instead of 532 at 32768 (section 5 of that profile).
 #ifndef ACCBLAS_TRSV_WIDE_FRONT_LOOP
 #define ACCBLAS_TRSV_WIDE_FRONT_LOOP 1
 #endif
-        // (2-byte storage, upper: 129 -> 209 us at n = 8192 with it; its ring
-        // is three deep and its tiles half as large - not looked into)
+        // (2-byte storage: 129 -> 209 us at n = 8192 upper, 324 -> 348 at 24000
+        // lower with it; its ring is three deep and its tiles half as large -
+        // not looked into)
         if constexpr ((ACCBLAS_TRSV_WIDE_FRONT_LOOP == 2 ||
-                       (ACCBLAS_TRSV_WIDE_FRONT_LOOP == 1 && Upper &&
+                       (ACCBLAS_TRSV_WIDE_FRONT_LOOP == 1 &&
                         sizeof(st_type) == 4)) &&
                       PPB == 1) {
             // catch up with what is published in chunks, then follow the front

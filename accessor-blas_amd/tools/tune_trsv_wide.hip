@@ -49,6 +49,9 @@ __global__ void fill(st_type *p, size_t n, unsigned seed, float scale)
 
 int main(int argc, char **argv)
 {
+    // (UPLO=upper in the environment: the mirrored solve)
+    const char *uplo_env = std::getenv("UPLO");
+    const bool upper_solve = uplo_env != nullptr && std::string(uplo_env) == "upper";
     const long n = argc > 1 ? std::atol(argv[1]) : 65536;
     const int rounds = argc > 2 ? std::atoi(argv[2]) : 5;
     st_type *A, *x, *x0;
@@ -95,8 +98,8 @@ int main(int argc, char **argv)
                 split.last_parts);
     struct entry { std::string name; std::function<void()> run; };
     std::vector<entry> entries = {
-        {"rows64", [&]() { CHECK(launch_trsv<ar_type>(false, true, m, xv, helper, session, nullptr, 1)); }},
-        {"rows128", [&]() { CHECK(launch_trsv_wide_split<ar_type>(false, true, m, xv, helper, session, nullptr, split, 256)); }},
+        {"rows64", [&]() { CHECK(launch_trsv<ar_type>(upper_solve, true, m, xv, helper, session, nullptr, 1)); }},
+        {"rows128", [&]() { CHECK(launch_trsv_wide_split<ar_type>(upper_solve, true, m, xv, helper, session, nullptr, split, 256)); }},
     };
     hipEvent_t start, stop;
     CHECK(hipEventCreate(&start));
