@@ -69,6 +69,10 @@ int trsv_split_from_option_value();
 int trsv_prefetch_option_value();
 /** Option "trsv_relay": 0 never, 1 by the measured rule (default), 2 always. */
 int trsv_relay_option_value();
+/** Option "trsv_vector_rows": 0 = 16-byte loads of the matrix only for
+ *  16-byte aligned bases and row strides (the rule until round 3), 1 = for
+ *  every operand (default). */
+int trsv_vector_rows_option_value();
 /** Option "trsv_small": 0 = the blocked kernels at every size, 1 = systems of
  *  at most 128 unknowns by one workgroup without a workspace (default). */
 int trsv_small_option_value();
@@ -134,8 +138,9 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
     // the key the launch's workgroups recognise each other by (`trsv_state`)
     session.serial = dev::trsv_next_serial();
     const int wide = trsv_wide_option_value();
+    const bool any_alignment = trsv_vector_rows_option_value() != 0;
     const bool use_wide =
-        wide != 0 && dev::trsv_wide_applicable(upper, mtx) &&
+        wide != 0 && dev::trsv_wide_applicable(upper, mtx, any_alignment) &&
         (wide == 2 ||
          (n >= ACCBLAS_TRSV_WIDE_MIN_N && sizeof(st_type) < 8));
     if (use_wide) {
@@ -150,7 +155,7 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
     return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x, helper,
                                                session, as_stream(stream),
                                                trsv_relay_option_value(),
-                                               trsv_num_cus()),
+                                               trsv_num_cus(), any_alignment),
                      "trsv launch");
 }
 

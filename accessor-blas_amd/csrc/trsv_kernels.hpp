@@ -200,6 +200,33 @@ constexpr index_type trsv_virtual_pad(bool upper, index_type n)
 }
 
 
+/**
+ * Whether the sweeps may read the rows of `mtx` with 16-byte loads. The
+ * hardware needs no alignment for them (the queues run in unaligned mode; the
+ * compiler emits the same `global_load_dwordx4` whatever alignment the pointer
+ * type promises), so any base and any row stride qualify. A load that is not
+ * 16-byte aligned may lie across two cache lines and is then served as two
+ * requests - with an odd row stride that is the case for some rows and not
+ * for others -, which costs a few per cent; the element-wise kernels (Vec = 1)
+ * that served such operands until round 3 issued four to eight times the
+ * load instructions and were 48 % slower at n = 24000 (fp32 storage,
+ * lda = n + 1: profiles/r04_trsv_odd_strides.txt). `any_alignment` = false
+ * restores that rule (option "trsv_vector_rows" = 0).
+ */
+template <typename MtxView>
+bool trsv_vector_rows(const MtxView &mtx, bool any_alignment)
+{
+    using mtx_traits = view_traits<MtxView>;
+    using st_type = std::remove_cv_t<typename mtx_traits::storage_type>;
+    constexpr int vec16 = 16 / sizeof(st_type);
+    if (any_alignment) {
+        return is_aligned(mtx_traits::data(mtx), sizeof(st_type));
+    }
+    return is_aligned(mtx_traits::data(mtx), 16) &&
+           mtx_traits::stride(mtx) % vec16 == 0;
+}
+
+
 namespace kernel {
 
 
@@ -748,9 +775,8 @@ __device__ __forceinline__ void invert_tile64(ar_type *tile, ar_type *scratch_a,
  * i' in [64 b, 64 b + 63]; entries with i' >= n do not exist (masked).
  * Granules are indexed by the logical element index.
  *
- * Vec = elements per 16-byte load in the far sweep (requires the matrix base
- * and row stride aligned to 16 bytes, and for Upper n % Vec == 0); Vec = 1 is
- * the fallback for any stride / alignment.
+ * Vec = elements per 16-byte load in the far sweep (any base and row stride,
+ * see `trsv_vector_rows`); Vec = 1 reads element by element.
  *
  * Meaning per block as in `cuda/trsv_kernels.cuh:527-692` (lower) /
  * `:725-893` (upper): x_b = inv(T_bb) * (x_b - sum_{c<b} A_bc x_c), all in
@@ -1582,7 +1608,8 @@ template <typename ArType, typename MtxView, typename XView>
 hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
                        const XView &x, std::uint32_t *helper,
                        const trsv_session &session, hipStream_t stream,
-                       int relay_mode = 1, int num_cus = 0)
+                       int relay_mode = 1, int num_cus = 0,
+                       bool any_alignment = true)
 {
     using mtx_traits = view_traits<MtxView>;
     using st_type =
@@ -1613,8 +1640,7 @@ hipError_t launch_trsv(bool upper, bool unit_diag, const MtxView &mtx,
     const unsigned pad = relay ? trsv_single_block_pad<ArType, waves, true>()
                                : trsv_single_block_pad<ArType, waves, false>();
     // (upper solves of any n: the vector path mirrors around a virtual size)
-    const bool vec_ok = is_aligned(mtx_traits::data(mtx), 16) &&
-                        mtx_traits::stride(mtx) % vec16 == 0;
+    const bool vec_ok = trsv_vector_rows(mtx, any_alignment);
     // (the vector path of an upper solve is laid out for a virtual size)
     // one workgroup per row block, but no more than one per CU: workgroups
     // draw tickets until none is left (see the kernel)

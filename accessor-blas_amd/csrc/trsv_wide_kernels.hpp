@@ -350,8 +350,8 @@ __device__ __forceinline__ T inverse_row_times(const T *x00, const T *x11,
  * Blocked triangular solve with 128-row blocks. blockDim = 512,
  * grid = ceil(n / 128). Index mapping (`phys`), granule indexing, tags and
  * the workspace protocol are those of `kernel::trsv`; both kernels can share
- * one workspace. Vec = elements per 16-byte load (the matrix base and row
- * stride must be 16-byte aligned, for Upper n % Vec == 0). PanelCols = columns
+ * one workspace. Vec = elements per 16-byte load (any matrix base and row
+ * stride, see `trsv_vector_rows`). PanelCols = columns
  * a wave sweeps per step (128, or 64 to halve the registers of a stage),
  * Depth = steps in flight per wave, DeepDepth = the same while the folded
  * panel W is not yet computed (long sweeps defer it).
@@ -1681,17 +1681,15 @@ constexpr unsigned trsv_wide_single_block_pad()
 }
 
 
-/** Operands the 128-row kernel takes: 16-byte aligned matrix base and row
- *  stride. */
+/** Operands the 128-row kernel takes: those whose rows the sweeps may read
+ *  with 16-byte loads (`trsv_vector_rows`: any since round 4; only aligned
+ *  bases and row strides with `any_alignment` = false). */
 template <typename MtxView>
-bool trsv_wide_applicable(bool upper, const MtxView &mtx)
+bool trsv_wide_applicable(bool upper, const MtxView &mtx,
+                          bool any_alignment = true)
 {
-    using mtx_traits = view_traits<MtxView>;
-    using st_type = std::remove_cv_t<typename mtx_traits::storage_type>;
-    constexpr int vec16 = 16 / sizeof(st_type);
     (void)upper;  // (upper solves of any n: mirrored around a virtual size)
-    return is_aligned(mtx_traits::data(mtx), 16) &&
-           mtx_traits::stride(mtx) % vec16 == 0;
+    return trsv_vector_rows(mtx, any_alignment);
 }
 
 

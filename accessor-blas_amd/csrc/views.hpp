@@ -159,9 +159,16 @@ __host__ __device__ constexpr index_type ceildiv(index_type a, index_type b)
 template <typename T, int N>
 struct packed {
     typedef T type __attribute__((ext_vector_type(N)));
+    // the same vector where only its elements are known to be aligned
+    typedef T loose_type
+        __attribute__((ext_vector_type(N), aligned(sizeof(T))));
 };
 
-/** Streaming load of N storage elements; `ptr` must be N*sizeof(T) aligned.
+/** Streaming load of N storage elements by one instruction. `ptr` need only be
+ *  aligned like an element (the queues run in the hardware's unaligned mode and
+ *  the instruction is the same either way); a load that is not N*sizeof(T)
+ *  aligned may lie across two cache lines and then costs two requests - GEMV
+ *  and dot peel to an aligned start, the TRSV sweeps take rows as they come.
  *  NT = non-temporal hint (`global_load_dwordx4 ... nt`) for data that is
  *  read exactly once (the matrix in GEMV/TRSV, both vectors in dot). */
 template <int N, bool NT, typename T>
@@ -169,7 +176,8 @@ __device__ __forceinline__ typename packed<std::remove_cv_t<T>, N>::type
 load_packed(const T *ptr)
 {
     using vec_type = typename packed<std::remove_cv_t<T>, N>::type;
-    const auto *vptr = reinterpret_cast<const vec_type *>(ptr);
+    using loose_type = typename packed<std::remove_cv_t<T>, N>::loose_type;
+    const auto *vptr = reinterpret_cast<const loose_type *>(ptr);
     if (NT) {
         return __builtin_nontemporal_load(vptr);
     }

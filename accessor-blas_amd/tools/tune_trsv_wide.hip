@@ -27,7 +27,10 @@
     } while (0)
 
 using namespace accblas::dev;
-using ar_type = double;
+#ifndef TUNE_AR_TYPE
+#define TUNE_AR_TYPE double
+#endif
+using ar_type = TUNE_AR_TYPE;
 #ifndef TUNE_ST_TYPE
 #define TUNE_ST_TYPE float
 #endif

@@ -84,7 +84,7 @@ size_t accblas_dtype_size(accblas_dtype t);
  * compile-time constants). The knobs take 0, 1 or 2 unless said otherwise.
  * Known names:
  *   "trsv_wide"   1 (default) = systems of 2- or 4-byte storage with
- *                 n >= 4096 and a 16-byte aligned matrix base and row stride use
+ *                 n >= 4096 use
  *                 128-row blocks (`kernel::trsv_wide`: half as many dependent
  *                 hops through memory, the folded panel held in registers),
  *                 everything else - 8-byte storage at every size - 64-row blocks
@@ -99,6 +99,11 @@ size_t accblas_dtype_size(accblas_dtype t);
  *                 one workgroup without a workspace (`kernel::trsv_small`:
  *                 forward substitution in the wave; any alignment, row stride
  *                 and increment); 0 = the blocked kernels at every size.
+ *   "trsv_vector_rows"  1 (default) = the blocked TRSV kernels read the matrix
+ *                 with 16-byte loads whatever its base address and row stride
+ *                 (the hardware takes them at any alignment); 0 = only for
+ *                 16-byte aligned bases and strides, other operands run the
+ *                 element-wise 64-row kernel (the rule until round 3).
  *   "gemv_skew"   1 (default) = GEMV with fp64 arithmetic and a power-of-two
  *                 row pitch (>= 16 KiB) uses the time-skewed sweep (rows of
  *                 a group walk the columns one chunk apart, against channel

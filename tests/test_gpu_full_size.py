@@ -364,6 +364,45 @@ def test_trsv_both_block_sizes_match_oracle(gpu, wide, upper, unit, ar, st):
     assert torch.equal(dx, dx2)
 
 
+@pytest.mark.parametrize("vector_rows", [1, 0])
+@pytest.mark.parametrize("wide", [1, 2])
+@pytest.mark.parametrize("upper", [False, True])
+@pytest.mark.parametrize("ar,st", [(F64, F32), (F32, F32), (F64, F16), (F64, F64)])
+def test_trsv_odd_row_stride_and_misaligned_base(gpu, vector_rows, wide, upper, ar, st):
+    """A matrix view the reference's `stride` argument allows and its benchmark never
+    builds (`cuda/trsv_kernels.cuh:918-933`): an odd row stride (12303) from a base one
+    element off its allocation, n = 12301. Since round 4 the blocked kernels read such
+    rows with the same 16-byte loads as aligned ones (some then lie across two cache
+    lines; option "trsv_vector_rows" = 0: the element-wise kernel of round 3). Both
+    against the semantic oracle, non-unit diagonal."""
+    torch, accblas = gpu
+    n, lda, offset = 12301, 12303, 1
+    rng = np.random.default_rng(78)
+    full = rng.uniform(-1.0, 1.0, (n, lda)) / np.sqrt(n)
+    full[np.arange(n), np.arange(n)] = rng.uniform(1.0, 2.0, n)
+    A = oracle.convert(np.concatenate([np.full(offset, 1e3), full.reshape(-1)]), st)
+    b = oracle.convert(rng.uniform(-1.0, 1.0, n), st)
+    want = oracle.exact_trsv(ar, upper, False, n, A[offset:], lda, b, 1)
+    dA = torch.from_numpy(A).cuda()
+    dx = torch.from_numpy(b).cuda()
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    accblas.set_option("trsv_wide", wide)
+    accblas.set_option("trsv_vector_rows", vector_rows)
+    try:
+        accblas.acc_trsv(ar, st, accblas.UPPER if upper else accblas.LOWER, accblas.NON_UNIT, n,
+                         dA[offset:], lda, dx, 1, helper)
+        torch.cuda.synchronize()
+    finally:
+        accblas.set_option("trsv_wide", 1)
+        accblas.set_option("trsv_vector_rows", 1)
+    assert int(helper[0].item()) & 0xffffffff == 0xffffffff
+    got = dx.cpu().numpy()
+    err = oracle.rel_error(want.astype(np.float64), got.astype(np.float64))
+    tol = {F16: 1e-1, F32: 1e-5 if ar == F64 else 5e-4, F64: 1e-11}[st]
+    assert err <= tol, err
+    assert float(dA[0].item()) == 1e3  # (nothing wrote in front of the view)
+
+
 @pytest.mark.parametrize("ar,st,n,tol", [
     (F64, F64, 18000, 1e-12),   # fp64 storage beyond 17000 unknowns: loader-wave variant
     (F64, F64, 16001, 1e-12),   # just below: direct variant, ragged last block

@@ -375,8 +375,9 @@ TRSV_SIZES = [(1, 1), (31, 40), (64, 64), (65, 100), (100, 24000 // 8), (128, 12
               # n off the vector length with a row stride the vector paths take:
               # an upper solve then has a vector across its first real column
               (267, 272), (1001, 1008), (2051, 2112),
-              # packed matrices whose row stride is off the vector length (the
-              # 64-row kernel's scalar path; 8-byte vectors were measured: no gain)
+              # packed matrices whose row stride is off the vector length: 16-byte
+              # loads that are not 16-byte aligned (until round 3: the 64-row
+              # kernel's element-wise path, option "trsv_vector_rows" = 0)
               (270, 270), (1002, 1002), (1004, 1004)]
 
 
@@ -387,8 +388,7 @@ TRSV_SIZES = [(1, 1), (31, 40), (64, 64), (65, 100), (100, 24000 // 8), (128, 12
 @pytest.mark.parametrize("n,lda", TRSV_SIZES)
 def test_acc_trsv_matches_oracle(gpu, trsv_kernel, ar, st, upper, unit, n, lda):
     """Every kernel family (64-row blocks direct / through the loader wave,
-    128-row blocks; operands a family cannot take fall back to the 64-row
-    scalar path) x every (arithmetic, storage) pair against both oracle levels."""
+    128-row blocks) x every (arithmetic, storage) pair against both oracle levels."""
     torch, accblas = gpu
     A = oracle.convert(triangular_system(n, lda, upper, 30 + n), st)
     b = make_inputs(31, n, st)

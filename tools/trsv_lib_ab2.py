@@ -42,7 +42,8 @@ helper = torch.zeros(2, dtype=torch.int32, device="cuda")
 print(f"st={st_name} ar={os.environ.get('AR', 'f64')} {'upper' if UPLO == 0 else 'lower'} reps={reps}; per build: min / median us", flush=True)
 for n in sizes:
     scale = 1.0 / n ** 0.5
-    lda = max(n, int(os.environ.get("LDA", "0")))  # (LDA in the environment: row stride, as the CLIs' sweeps have it)
+    # (LDA in the environment: row stride, as the CLIs' sweeps have it; LDA_PLUS: lda = n + that, e.g. an odd stride)
+    lda = max(n, int(os.environ.get("LDA", "0"))) + int(os.environ.get("LDA_PLUS", "0"))
     A = torch.rand(n * lda, dtype=torch.float32, device="cuda").mul_(2 * scale).sub_(scale).to(st_torch)
     x0 = torch.rand(n, dtype=torch.float32, device="cuda").mul_(2).sub_(1).to(st_torch)
     x = x0.clone()
