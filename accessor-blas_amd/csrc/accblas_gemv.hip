@@ -71,7 +71,8 @@ int accblas_gemv(accblas_dtype vt, int64_t rows, int64_t cols, double alpha,
         return accblas::check_hip(
             launch_gemv(static_cast<value_type>(alpha), m_view, x_view,
                         static_cast<value_type>(beta), res_view,
-                        accblas::as_stream(stream), accblas::gemv_skew_option()),
+                        accblas::as_stream(stream), accblas::gemv_skew_option(),
+                        accblas::gemv_vector_rows_option_value() != 0),
             "gemv launch");
     });
 }
@@ -112,7 +113,8 @@ int accblas_acc_gemv(accblas_dtype ar, accblas_dtype st, int64_t rows,
                 accblas::dev::launch_gemv(static_cast<ar_type>(alpha), m_acc,
                                           x_acc, static_cast<ar_type>(beta),
                                           res_acc, accblas::as_stream(stream),
-                                          accblas::gemv_skew_option()),
+                                          accblas::gemv_skew_option(),
+                                          accblas::gemv_vector_rows_option_value() != 0),
                 "acc_gemv launch");
         });
     });

@@ -74,6 +74,9 @@ int dispatch_arithmetic(accblas_dtype t, F &&f)
 /** Option "gemv_skew" (accblas_set_option; defined in accblas_trsv.hip next
  *  to the other options): 0 never, 1 automatic (default), 2 always. */
 int gemv_skew_option_value();
+/** Option "gemv_vector_rows": 0 = 16-byte loads only for 16-byte aligned
+ *  operands (the rule until round 3), 1 = for every operand (default). */
+int gemv_vector_rows_option_value();
 
 inline hipStream_t as_stream(void *stream)
 {

@@ -19,9 +19,14 @@ std::atomic<int> trsv_prefetch_option{1};
 std::atomic<int> trsv_small_option{1};
 std::atomic<int> trsv_vector_rows_option{1};
 std::atomic<int> gemv_skew_option_store{1};
+std::atomic<int> gemv_vector_rows_option{1};
 }
 
 int accblas::gemv_skew_option_value() { return gemv_skew_option_store.load(); }
+int accblas::gemv_vector_rows_option_value()
+{
+    return gemv_vector_rows_option.load();
+}
 int accblas::trsv_wide_option_value() { return trsv_wide_option.load(); }
 int accblas::trsv_relay_option_value() { return trsv_relay_option.load(); }
 int accblas::trsv_split_from_option_value()
@@ -81,6 +86,8 @@ extern "C" int accblas_set_option(const char *name, int value)
         target = &trsv_small_option;
     } else if (key == "trsv_vector_rows") {
         target = &trsv_vector_rows_option;
+    } else if (key == "gemv_vector_rows") {
+        target = &gemv_vector_rows_option;
     } else if (key == "gemv_skew") {
         target = &gemv_skew_option_store;
     } else {

@@ -560,7 +560,8 @@ template <typename Config = gemv_default_config, typename ArType,
           typename MtxView, typename XView, typename ResView>
 hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
                        ArType beta, const ResView &res, hipStream_t stream,
-                       gemv_skew_mode skew_mode = gemv_skew_mode::automatic)
+                       gemv_skew_mode skew_mode = gemv_skew_mode::automatic,
+                       bool any_alignment = true)
 {
     using mtx_traits = view_traits<MtxView>;
     using x_traits = view_traits<XView>;
@@ -593,8 +594,24 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
     if constexpr (!pointer_views) {
         launch_generic();
     } else {
-        if (lda % vec16 == 0 && is_aligned(a_ptr, 16)) {
-            if (unit_x && is_aligned(x_ptr, 16)) {
+        // 16-byte loads need no alignment (`load_packed`): rows and x are taken
+        // as they come. Until round 3 (`any_alignment` = false) operands that
+        // were not 16-byte aligned ran with 8-byte loads or element-wise: an odd
+        // row stride cost 25 % (fp32 storage) to 35 % (fp64) at n = 24501
+        // (profiles/r04_gemv_odd_strides.txt).
+        const bool a_aligned = lda % vec16 == 0 && is_aligned(a_ptr, 16);
+        const bool x_vectors =
+            unit_x && (is_aligned(x_ptr, 16) ||
+                       (any_alignment && is_aligned(x_ptr, sizeof(st_type))));
+        // (short unaligned rows of 2- and 4-byte storage stay with the
+        // element-wise kernel: 2049 / 4097 columns 6.5 / 14.0 us against 7.4 /
+        // 15.3 with vectors across cache lines, 8001 columns 40.1 against 37.9)
+        const bool a_vectors =
+            a_aligned ||
+            (any_alignment && x_vectors && is_aligned(a_ptr, sizeof(st_type)) &&
+             (sizeof(st_type) == 8 || mtx.length(1) >= 6144));
+        if (a_vectors) {
+            if (x_vectors) {
                 // power-of-two row pitch and fp64 arithmetic: time-skewed
                 // rows (see the kernel); with fp32 arithmetic the plain sweep
                 // is the faster one (612 vs 622 us at 32768^2)
@@ -631,12 +648,14 @@ hipError_t launch_gemv(ArType alpha, const MtxView &mtx, const XView &x,
                     kernel::gemv_vec<skew, vec16, true, true, false>
                         <<<skew_grid, dim3(skew::waves * wave_size), 0,
                            stream>>>(alpha, mtx, x, beta, res);
-                } else if (pitch_bytes % 128 != 0 &&
+                } else if ((pitch_bytes % 128 != 0 || !a_aligned) &&
                            cols >= 12 * row_align_iter_cols) {
                     // rows start inside cache lines: per-row aligned grids
                     // (24500^2 fp32: 357 -> 339 us; below ~12 steps per row
                     // the element-wise head and tail cost more than the
-                    // alignment gains)
+                    // alignment gains). Rows that are not even 16-byte aligned
+                    // get aligned matrix loads this way as well; only x is
+                    // then read across its 16-byte boundaries.
                     using aligned = gemv_row_align_config;
                     const dim3 aligned_grid(
                         static_cast<unsigned>(

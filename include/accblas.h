@@ -104,6 +104,10 @@ size_t accblas_dtype_size(accblas_dtype t);
  *                 (the hardware takes them at any alignment); 0 = only for
  *                 16-byte aligned bases and strides, other operands run the
  *                 element-wise 64-row kernel (the rule until round 3).
+ *   "gemv_vector_rows"  the same for GEMV: 1 (default) = rows (and x) of any
+ *                 alignment are read with 16-byte loads - long rows on their
+ *                 own 128-byte aligned column grid -; 0 = 8-byte loads or the
+ *                 element-wise kernel for operands that are not 16-byte aligned.
  *   "gemv_skew"   1 (default) = GEMV with fp64 arithmetic and a power-of-two
  *                 row pitch (>= 16 KiB) uses the time-skewed sweep (rows of
  *                 a group walk the columns one chunk apart, against channel

@@ -61,8 +61,12 @@ GEMV_SHAPES = [
     (513, 1000, 1024, 0),
     (64, 4096, 4096, 0),
     (2048, 2048, 2048, 0),
-    (130, 1027, 1031, 0),  # lda odd -> generic path
-    (200, 512, 520, 1),    # misaligned base -> narrower / generic path
+    # rows that are not 16-byte aligned: 16-byte loads all the same since round 4
+    # (until then: 8-byte loads / the element-wise kernel, option "gemv_vector_rows" = 0)
+    (130, 1027, 1031, 0),  # lda odd
+    (200, 512, 520, 1),    # misaligned base
+    (37, 13001, 13003, 1),  # both, long rows: every row on its own 128-byte aligned grid
+    (9, 26001, 26003, 3),
     (3, 70000, 70000, 0),  # few long rows
     (37, 13000, 13004, 0),  # pitch not a multiple of 128 bytes: per-row aligned grids
     (9, 26001, 26004, 0),
