@@ -177,8 +177,8 @@ __global__ __launch_bounds__(64) void cast_result(const InType *in,
 
 
 /**
- * Grid-stride dot product. Vec > 1 requires both storage pointers aligned to
- * Vec*sizeof(St) and unit increments (checked by the launcher); Vec == 1 goes
+ * Grid-stride dot product. Vec > 1 requires unit increments and plain storage
+ * of one type (checked by the launcher; any base address); Vec == 1 goes
  * through operator() only and works for any increment.
  *
  * Atomic == false: tagged slot per workgroup, collected by the last workgroup
@@ -409,10 +409,13 @@ hipError_t launch_dot_with(dot_workspace &ws, bool atomic,
         std::is_same<st_type, std::remove_cv_t<
                                   typename y_traits::storage_type>>::value;
     constexpr int vec = can_vec ? vec16 : 1;
+    // (any base: the 16-byte loads need no alignment, `load_packed`; a
+    // subvector that starts off a 16-byte boundary ran element-wise until
+    // round 3, profiles/r04_dot_unaligned.txt)
     const bool vec_ok = can_vec && (x_traits::stride(x) == 1 || n <= 1) &&
                         (y_traits::stride(y) == 1 || n <= 1) &&
-                        is_aligned(x_traits::data(x), 16) &&
-                        is_aligned(y_traits::data(y), 16);
+                        is_aligned(x_traits::data(x), sizeof(st_type)) &&
+                        is_aligned(y_traits::data(y), sizeof(st_type));
     if (atomic) {
         // reference sequence: init_res -> dot (atomic_add) -> cast_result
         constexpr bool direct = std::is_same<ArType, ResType>::value;

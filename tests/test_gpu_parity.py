@@ -282,6 +282,28 @@ def test_acc_dot_matches_oracle(gpu, ar, st, n, mode):
     handle.close()
 
 
+@pytest.mark.parametrize("ar,st", PAIRS)
+@pytest.mark.parametrize("x_offset,y_offset", [(1, 0), (3, 1)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_acc_dot_of_subvectors_off_the_vector_alignment(gpu, ar, st, x_offset, y_offset, mode):
+    """Subvectors that start off a 16-byte boundary (a view into a larger vector,
+    `cuda/dot_kernels.cuh:209-240` builds the ranges from whatever pointers it is
+    given): the same 16-byte loads since round 4, element-wise until then."""
+    torch, accblas = gpu
+    handle = accblas.Handle()
+    handle.set_dot_mode(mode)
+    n = 1_000_003
+    x = make_inputs(26, n + x_offset, st)
+    y = make_inputs(27, n + y_offset, st)
+    want, scale = oracle.exact_dot(ar, n, x[x_offset:], 1, y[y_offset:], 1)
+    res = torch.zeros(1, dtype=accblas.torch_dtype(ar), device="cuda")
+    accblas.acc_dot(handle, ar, st, ar, n, to_dev(torch, x)[x_offset:], 1,
+                    to_dev(torch, y)[y_offset:], 1, res)
+    torch.cuda.synchronize()
+    assert abs(float(res.item()) - want) <= 64 * EPS[ar] * scale + 1e-300
+    handle.close()
+
+
 @pytest.mark.parametrize("vt", [F32, F64])
 def test_plain_dot_equals_accessor_bitwise(gpu, vt):
     torch, accblas = gpu
