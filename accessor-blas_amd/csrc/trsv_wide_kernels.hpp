@@ -1213,8 +1213,21 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
 #ifndef ACCBLAS_TRSV_WIDE_DEFERRED_REFILL
 #define ACCBLAS_TRSV_WIDE_DEFERRED_REFILL 1
 #endif
-            if (ACCBLAS_TRSV_WIDE_DEFERRED_REFILL != 0 && c >= 1 &&
-                c - 1 + Depth < far_end) {
+            // (`refill`: a literal `true` in the main loop below, where the
+            // step exists - the request is then unconditional and lands in the
+            // slot's own registers. Behind a condition the slot is a phi of
+            // "loaded" and "kept": with fp32 arithmetic the compiler loaded
+            // into other registers and copied them over behind a full wait -
+            // in front of the barrier all eight waves meet at -, and the blocks
+            // saw x_{b-2} 1.5-1.8 us after its publication instead of 0.8,
+            // profiles/r04_trsv_wide_front.txt section 6)
+            // (fp64 arithmetic keeps the condition: its compiler output
+            // branches around the loads, no copies, and without the condition
+            // the upper instantiations spill - n = 24000: 335 -> 547 us)
+            constexpr bool plain_refill = sizeof(ar_type) < 8;
+            if (ACCBLAS_TRSV_WIDE_DEFERRED_REFILL != 0 &&
+                (plain_refill ? (refill || c - 1 + Depth < far_end)
+                              : (c >= 1 && c - 1 + Depth < far_end))) {
                 issue(c - 1 + Depth, previous);
             }
         }
@@ -1275,7 +1288,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             // first step, as of every later one)
             if (begin + d < end &&
                 !(ACCBLAS_TRSV_WIDE_DEFERRED_REFILL != 0 && Poller &&
-                  d == D - 1 && begin >= 1)) {
+                  d == D - 1 && (sizeof(ar_type) < 8 || begin >= 1))) {
                 issue(begin + d, ring[d]);
             }
         }

@@ -24,6 +24,14 @@ hipError_t wide(const c_range &m, const range &x, std::uint32_t *helper, const t
 {
     return launch_trsv_wide<double>(false, true, m, x, helper, s, nullptr, 256);
 }
+// fp32 arithmetic on fp32 storage (the reference's plain `trsv<float>` column)
+using acc32 = gko::acc::reduced_row_major<2, float, float>;
+using range32 = gko::acc::range<acc32>;
+using c_range32 = gko::acc::range<acc32::const_accessor>;
+hipError_t wide32(const c_range32 &m, const range32 &x, std::uint32_t *helper, const trsv_session &s)
+{
+    return launch_trsv_wide<float>(true, true, m, x, helper, s, nullptr, 256);
+}
 hipError_t narrow(const c_range &m, const range &x, std::uint32_t *helper, const trsv_session &s)
 {
     return launch_trsv<double>(false, true, m, x, helper, s, nullptr, 0);
@@ -93,7 +101,7 @@ def test_trsv_tile_staging_is_one_batch_of_loads_and_nothing_spills(tmp_path):
     found = kernels(asm)
     wide = {k: v for k, v in found.items() if "9trsv_wide" in k}
     narrow = {k: v for k, v in found.items() if "kernel4trsv" in k}
-    assert len(wide) == 4 and narrow, sorted(found)
+    assert len(wide) == 8 and narrow, sorted(found)  # (uplo x diag) x (fp64, fp32 arithmetic)
     for name, body in wide.items():
         # between the ticket barrier and the "tiles staged" barrier: 3 tiles x
         # 8 rows per wave plus the block's own right-hand side, one batch
