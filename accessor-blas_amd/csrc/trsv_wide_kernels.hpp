@@ -940,8 +940,12 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     const index_type far_end = far_columns * PPB;    // steps below far_end
     const int row_in_inst = lane / LPR;
     const int col_group = lane % LPR;
+    // (a step's matrix data as loaded: the elements are taken apart where they
+    // are used. Taken apart where they are loaded - `a[k][e] = v[e]` -, the
+    // halves of 2-byte storage cost a shift each right behind the load, in the
+    // loop's latch: a full wait per round of the ring)
     struct stage {
-        st_type a[NI][Vec];
+        typename packed<st_type, Vec>::type a[NI];
     };
     // (the NI row pointers of a step are formed where they are used, one
     // multiply-add each: as an array they are 16 registers that live through
@@ -969,11 +973,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                   : first_col;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
-            const auto v = load_packed<Vec, ACCBLAS_TRSV_NT>(row_ptr(k) + mem_col);
-#pragma unroll
-            for (int e = 0; e < Vec; ++e) {
-                s.a[k][e] = v[e];
-            }
+            s.a[k] = load_packed<Vec, ACCBLAS_TRSV_NT>(row_ptr(k) + mem_col);
         }
     };
     ar_type acc[NI];
