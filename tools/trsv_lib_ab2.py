@@ -76,6 +76,11 @@ for n in sizes:
             if first[i] is None:
                 first[i] = x.clone()
             assert torch.equal(first[i], x), f"{names[i]} is not repeatable"
+    # SAME_BITS=1 in the environment: every build must give the first one's bits (builds that differ in
+    # waiting and scheduling only)
+    same = all(torch.equal(first[0], other) for other in first[1:])
+    assert same or os.environ.get("SAME_BITS", "0") == "0", "builds differ in their results"
     print(f"n={n:6d} " + "  ".join(f"{names[i]}: {min(t):7.1f} / {statistics.median(t):7.1f}"
-                                   for i, t in enumerate(times)), flush=True)
+                                   for i, t in enumerate(times)) +
+          ("" if len(libs) < 2 else ("   [same bits]" if same else "   [bits differ]")), flush=True)
     del A
