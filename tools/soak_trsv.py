@@ -37,27 +37,31 @@ def main(iterations=4000, seed=7, max_n=14000):
         family = int(rng.integers(0, 4))
         accblas.set_option("trsv_wide", (1, 0, 2, 2)[family])
         accblas.set_option("trsv_wide_split_from", 98 if family == 3 else 0)
-        A = mats[st]
+        # every third solve on a view that is not 16-byte aligned: a base a few
+        # elements into the allocation and an odd row stride
+        off, lda = (int(rng.integers(1, 8)), max_n - 1 - 2 * int(rng.integers(0, 3))) if it % 3 == 2 else (0, max_n)
+        n = min(n, lda - 8)
+        A = mats[st][off:]
         dtype = accblas.torch_dtype(st)
         with torch.cuda.stream(streams[which]):
             # operands are produced on the stream that consumes them
             b = (torch.rand(n, dtype=torch.float64, device="cuda") * 2 - 1).to(dtype)
             x = b.clone()
             accblas.acc_trsv(ar, st, accblas.UPPER if upper else accblas.LOWER,
-                             accblas.UNIT, n, A, max_n, x, 1, helpers[which], streams[which])
+                             accblas.UNIT, n, A, lda, x, 1, helpers[which], streams[which])
         if it % 200 == 199:
             torch.cuda.synchronize()
             for h in helpers:
                 assert int(h[0].item()) & 0xffffffff == 0xffffffff, f"spin expired at {it}"
             # residual of the last solve: T x = b with T = unit triangle of A[:n, :n]
-            T = A.view(max_n, max_n)[:n, :n].double()
+            T = torch.as_strided(A, (n, n), (lda, 1)).double()
             T = torch.triu(T, 1) if upper else torch.tril(T, -1)
             T = T + torch.eye(n, dtype=torch.float64, device="cuda")
             res = (T @ x.double() - b.double()).abs().sum() / b.double().abs().sum()
             worst = max(worst, float(res))
             tol = {F64: 1e-12, F32: 1e-5, F16: 2e-2}[st]
             assert float(res) <= tol, (it, n, st, ar, upper, float(res))
-            print(f"iteration {it + 1}: ok (n={n}, st={accblas.DTYPE_NAMES[st]}, "
+            print(f"iteration {it + 1}: ok (n={n}, lda={lda}, base+{off}, st={accblas.DTYPE_NAMES[st]}, "
                   f"residual {float(res):.2e})", flush=True)
     torch.cuda.synchronize()
     accblas.set_option("trsv_wide", 1)
