@@ -175,7 +175,6 @@ template <int N, bool NT, typename T>
 __device__ __forceinline__ typename packed<std::remove_cv_t<T>, N>::type
 load_packed(const T *ptr)
 {
-    using vec_type = typename packed<std::remove_cv_t<T>, N>::type;
     using loose_type = typename packed<std::remove_cv_t<T>, N>::loose_type;
     const auto *vptr = reinterpret_cast<const loose_type *>(ptr);
     if (NT) {
