@@ -483,3 +483,51 @@ def test_trsv_accessor_costs_nothing_over_plain_pointers(gpu, vt):
     assert torch.equal(bits["plain"], bits["acc"])
     ratio = min(times["acc"]) / min(times["plain"])
     assert abs(ratio - 1.0) <= 0.03, (ratio, times)
+
+
+def test_an_odd_row_stride_costs_gemv_nothing_and_trsv_little(gpu):
+    """What round 4 bought for operands that are not 16-byte aligned, timed on the CLIs'
+    own scale: the SAME product / solve on a view with lda = n + 1 starting one element
+    into its allocation, against the aligned view, alternated launch by launch, minimum
+    of 10 each. GEMV (every row then sweeps its own 128-byte aligned column grid): within
+    8 % (measured: equal); TRSV: within 25 % (measured: 12-15 %; the element-wise kernels
+    that served such views until round 3 were 25 % (GEMV) and 55-65 % (TRSV) slower,
+    profiles/r04_gemv_odd_strides.txt, r04_trsv_odd_strides.txt)."""
+    torch, accblas = gpu
+    n = 20000
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+    pool = uniform(torch, n * (n + 1) + 8, torch.float32, 81, scale=1.0 / n ** 0.5)
+    xg = uniform(torch, n + 8, torch.float32, 82)
+    res = torch.zeros(n, dtype=torch.float32, device="cuda")
+    x0 = uniform(torch, n, torch.float32, 83)
+    x = x0.clone()
+    views = {"aligned": (pool, n, xg), "odd": (pool[1:], n + 1, xg[1:])}
+
+    def gemv(which):
+        A, lda, xv = views[which]
+        accblas.acc_gemv(F64, F32, n, n, 1.0, A, lda, xv, 1, 0.0, res, 1)
+
+    def trsv(which):
+        A, lda, _ = views[which]
+        accblas.acc_trsv(F64, F32, accblas.UPPER, accblas.UNIT, n, A, lda, x, 1, helper)
+
+    def timed(fn, which, restore):
+        if restore:
+            x.copy_(x0)
+        torch.cuda.synchronize()
+        a, b = accblas.Event(), accblas.Event()
+        a.record()
+        fn(which)
+        b.record()
+        b.synchronize()
+        return a.elapsed_ms(b) * 1e3
+
+    for fn, restore, allowed in ((gemv, False, 1.08), (trsv, True, 1.25)):
+        best = {"aligned": 1e30, "odd": 1e30}
+        for rep in range(-1, 10):
+            for which in ("aligned", "odd"):
+                t = timed(fn, which, restore)
+                if rep >= 0:
+                    best[which] = min(best[which], t)
+        assert int(helper[0].item()) & 0xffffffff in (0, 0xffffffff)
+        assert best["odd"] <= allowed * best["aligned"], (fn.__name__, best)
