@@ -525,15 +525,20 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank, headline=None)
     # arithmetic fp64, and the reference CLI's default (upper / unit, n = 24000,
     # cuda/trsv_benchmark.cu:26-30); does not shard (replicas only): rank 0 only
     if rank == 0:
-        for n, uplo, uplo_name in ((65536, accblas.LOWER, "lower"),
-                                   (24000, accblas.UPPER, "upper")):
+        # (the third: the reference's plain `trsv<float>` column on the same problem)
+        for n, uplo, uplo_name, ar in ((65536, accblas.LOWER, "lower", F64),
+                                       (24000, accblas.UPPER, "upper", F64),
+                                       (24000, accblas.UPPER, "upper", F32)):
             L = uniform(n * n, torch.float32, scale=1.0 / n ** 0.5, seed=31)
             b = uniform(n, torch.float32, seed=32)
             xs = b.clone()
             helper = torch.zeros(2, dtype=torch.int32, device=dev)
 
             def solve():
-                accblas.acc_trsv(F64, F32, uplo, accblas.UNIT, n, L, n, xs, 1, helper, stream)
+                if ar == F64:
+                    accblas.acc_trsv(F64, F32, uplo, accblas.UNIT, n, L, n, xs, 1, helper, stream)
+                else:
+                    accblas.trsv(F32, uplo, accblas.UNIT, n, L, n, xs, 1, helper, stream)
             # the reference's protocol (warm-up, then the minimum of 10 runs,
             # cuda/utils.cuh:236-262) with x restored BEFORE the start event:
             # the bracket holds the solve's one launch and nothing else
@@ -551,7 +556,7 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank, headline=None)
             Lr = torch.where(keep, Lr, torch.zeros_like(Lr))
             resid = Lr @ xs.double() + xs.double()[rows] - b.double()[rows]
             byts = 4.0 * (n * (n - 1) / 2 + 2 * n)
-            out[f"trsv_{n}_{uplo_name}_unit_fp32_fp64"] = dict(
+            out[f"trsv_{n}_{uplo_name}_unit_fp32_{'fp64' if ar == F64 else 'plain_fp32'}"] = dict(
                 recomputable("accblas::dev::kernel::trsv_wide", byts, t_trsv, t_trsv_mean,
                              "x restored by a device copy enqueued before the start event; "
                              "warm-up, then min / mean of 10 event-timed solves (one launch "
