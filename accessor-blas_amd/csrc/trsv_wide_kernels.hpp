@@ -1121,11 +1121,30 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             begin_probe((cb + 1) / PPB);
         }
     };
+    // `value` "depends" on the accumulators: what is computed from it (the
+    // addresses of a refill) stays behind the FMAs that produce them
+    const auto order_after = [](index_type &value, ar_type (&sums)[NI]) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            asm volatile("" : "+v"(value) : "v"(sums[k]));
+        }
+    };
     // steps [begin, end) with `depth_tag` steps of matrix data in flight;
     // returns the first step it has not consumed: `end`, or - `until_front_tag`
     // = true - the step behind the one at which the workgroup reached the
     // chain's front (what the ring holds beyond it is dropped: the front loop
-    // below requests it again)
+    // below requests it again).
+    // Whole rounds of the ring whose refills all exist run WITHOUT a condition
+    // around the refill (`ACCBLAS_TRSV_WIDE_PLAIN_SWEEP`): behind `if (cb + D <
+    // end)` a slot is a phi of "loaded" and "kept", and the compiler loaded
+    // into spare registers and copied them into the slot behind `s_waitcnt
+    // vmcnt(7) ... vmcnt(0)` - right behind the step's FMAs, i.e. every step
+    // waited for the tile it had just requested and the ring was one step deep
+    // in time whatever its depth (the deferred sweep of a late row block, four
+    // steps on paper: profiles/r04_trsv_wide_sweep_ring.txt).
+#ifndef ACCBLAS_TRSV_WIDE_PLAIN_SWEEP
+#define ACCBLAS_TRSV_WIDE_PLAIN_SWEEP 1
+#endif
     const auto sweep = [&](auto depth_tag, auto until_front_tag,
                            index_type begin, index_type end) -> index_type {
         constexpr int D = decltype(depth_tag)::value;
@@ -1137,7 +1156,29 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                 issue(begin + d, ring[d]);
             }
         }
-        for (index_type cb0 = begin; cb0 < end; cb0 += D) {
+        index_type cb0 = begin;
+        // (the deep ring only - the bulk of a late row block's sweep, before
+        // its folded panel exists -: with the shallow sweeps written this way
+        // as well the lower instantiations spill 56 bytes and lose 5-12 %)
+        // (4-byte storage: n = 36000 lower 574 -> 542 us, upper 40000-49152 -1
+        // ... -3 %, 65536 unchanged; 2-byte storage loses 3-5 % with it)
+        if (ACCBLAS_TRSV_WIDE_PLAIN_SWEEP != 0 && D > Depth &&
+            sizeof(st_type) == 4) {
+            for (; cb0 + 2 * D <= end; cb0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const index_type cb = cb0 + d;
+                    consume(cb, ring[d]);
+                    if (until_front && at_front) {
+                        return cb + 1;
+                    }
+                    index_type next = cb + D;
+                    order_after(next, acc);
+                    issue(next, ring[d]);
+                }
+            }
+        }
+        for (; cb0 < end; cb0 += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const index_type cb = cb0 + d;
@@ -1153,14 +1194,6 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
             }
         }
         return end;
-    };
-    // `value` "depends" on the accumulators: what is computed from it (the
-    // addresses of a refill) stays behind the FMAs that produce them
-    const auto order_after = [](index_type &value, ar_type (&sums)[NI]) {
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            asm volatile("" : "+v"(value) : "v"(sums[k]));
-        }
     };
     // ---- the front loop: one block column per step, the chain's pace --------
     // A workgroup at the front gets one block column of x per hop. Every block
