@@ -1160,8 +1160,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
         // (the deep ring only - the bulk of a late row block's sweep, before
         // its folded panel exists -: with the shallow sweeps written this way
         // as well the lower instantiations spill 56 bytes and lose 5-12 %)
-        // (4-byte storage: n = 36000 lower 574 -> 542 us, upper 40000-49152 -1
-        // ... -3 %, 65536 unchanged; 2-byte storage loses 3-5 % with it)
+        // (4-byte storage: n = 36000 ... 49152 -1 ... -6 % depending on the box,
+        // 65536 unchanged; 2-byte storage loses 3-5 % with it)
         if (ACCBLAS_TRSV_WIDE_PLAIN_SWEEP != 0 && D > Depth &&
             sizeof(st_type) == 4) {
             for (; cb0 + 2 * D <= end; cb0 += D) {
