@@ -109,16 +109,25 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
         return ACCBLAS_OK;
     }
     const std::size_t bytes = dev::trsv_workspace_bytes<st_type>(n);
+    if (external != nullptr &&
+        static_cast<std::size_t>(external->capacity_words) *
+                sizeof(dev::granule_word) <
+            bytes) {
+        return set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
+                         "trsv: workspace smaller than "
+                         "accblas_trsv_workspace_bytes(st, n)");
+    }
+    if (n <= dev::trsv_small_max_n && trsv_small_option_value() != 0) {
+        // one workgroup, nothing handed over through memory: no workspace is
+        // leased (or allocated) for such a solve, the caller's stays untouched
+        return check_hip(dev::launch_trsv_small<ar_type>(upper, unit_diag, mtx,
+                                                         x, helper,
+                                                         as_stream(stream)),
+                         "trsv (one workgroup) launch");
+    }
     trsv_workspace_lease lease;
     dev::trsv_session session{};
     if (external != nullptr) {
-        if (static_cast<std::size_t>(external->capacity_words) *
-                sizeof(dev::granule_word) <
-            bytes) {
-            return set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
-                             "trsv: workspace smaller than "
-                             "accblas_trsv_workspace_bytes(st, n)");
-        }
         session = *external;
     } else {
         const int status = lease.acquire(as_stream(stream), bytes);
@@ -126,14 +135,6 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
             return status;
         }
         session = lease.session();
-    }
-    if (n <= dev::trsv_small_max_n && trsv_small_option_value() != 0) {
-        // one workgroup, nothing handed over through memory: the workspace
-        // (library-owned or the caller's) stays untouched
-        return check_hip(dev::launch_trsv_small<ar_type>(upper, unit_diag, mtx,
-                                                         x, helper,
-                                                         as_stream(stream)),
-                         "trsv (one workgroup) launch");
     }
     // the key the launch's workgroups recognise each other by (`trsv_state`)
     session.serial = dev::trsv_next_serial();
