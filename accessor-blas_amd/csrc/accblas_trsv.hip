@@ -16,6 +16,7 @@ std::atomic<int> trsv_wide_option{1};
 std::atomic<int> trsv_relay_option{1};
 std::atomic<int> trsv_split_from_option{0};
 std::atomic<int> trsv_prefetch_option{1};
+std::atomic<int> trsv_wide_persistent_option{0};
 std::atomic<int> trsv_small_option{1};
 std::atomic<int> trsv_vector_rows_option{1};
 std::atomic<int> gemv_skew_option_store{1};
@@ -36,6 +37,10 @@ int accblas::trsv_split_from_option_value()
 
 int accblas::trsv_prefetch_option_value() { return trsv_prefetch_option.load(); }
 int accblas::trsv_small_option_value() { return trsv_small_option.load(); }
+int accblas::trsv_wide_persistent_option_value()
+{
+    return trsv_wide_persistent_option.load();
+}
 int accblas::trsv_vector_rows_option_value()
 {
     return trsv_vector_rows_option.load();
@@ -82,6 +87,8 @@ extern "C" int accblas_set_option(const char *name, int value)
         target = &trsv_relay_option;
     } else if (key == "trsv_prefetch") {
         target = &trsv_prefetch_option;
+    } else if (key == "trsv_wide_persistent") {
+        target = &trsv_wide_persistent_option;
     } else if (key == "trsv_small") {
         target = &trsv_small_option;
     } else if (key == "trsv_vector_rows") {

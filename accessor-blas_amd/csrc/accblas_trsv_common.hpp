@@ -67,6 +67,10 @@ int trsv_split_from_option_value();
 /** Option "trsv_prefetch": 0 = no prefetching workgroups, 1 = by the measured
  *  rule (default, `trsv_wide_prefetchers_for`), 2 = whenever CUs are idle. */
 int trsv_prefetch_option_value();
+/** Option "trsv_wide_persistent": 0 = the 128-row kernel is launched with one
+ *  workgroup per ticket, 1 = with one workgroup per CU drawing tickets until
+ *  none is left when the solve has more tickets than CUs. */
+int trsv_wide_persistent_option_value();
 /** Option "trsv_relay": 0 never, 1 by the measured rule (default), 2 always. */
 int trsv_relay_option_value();
 /** Option "trsv_vector_rows": 0 = 16-byte loads of the matrix only for
@@ -150,7 +154,8 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
                                            session, as_stream(stream),
                                            trsv_num_cus(),
                                            trsv_split_from_option_value(),
-                                           trsv_prefetch_option_value()),
+                                           trsv_prefetch_option_value(),
+                                           trsv_wide_persistent_option_value()),
             "trsv (128-row) launch");
     }
     return check_hip(dev::launch_trsv<ar_type>(upper, unit_diag, mtx, x, helper,

@@ -347,21 +347,25 @@ __device__ __forceinline__ T inverse_row_times(const T *x00, const T *x11,
 
 
 /**
- * Blocked triangular solve with 128-row blocks. blockDim = 512,
- * grid = ceil(n / 128). Index mapping (`phys`), granule indexing, tags and
- * the workspace protocol are those of `kernel::trsv`; both kernels can share
- * one workspace. Vec = elements per 16-byte load (any matrix base and row
- * stride, see `trsv_vector_rows`). PanelCols = columns
- * a wave sweeps per step (128, or 64 to halve the registers of a stage),
- * Depth = steps in flight per wave, DeepDepth = the same while the folded
- * panel W is not yet computed (long sweeps defer it).
+ * One ticket's work of the blocked triangular solve with 128-row blocks (the
+ * body of `kernel::trsv_wide`, blockDim = 512). Index mapping (`phys`), granule
+ * indexing, tags and the workspace protocol are those of `kernel::trsv`; both
+ * kernels can share one workspace. Vec = elements per 16-byte load (any matrix
+ * base and row stride, see `trsv_vector_rows`). PanelCols = columns a wave
+ * sweeps per step (128, or 64 to halve the registers of a stage), Depth =
+ * steps in flight per wave, DeepDepth = the same while the folded panel W is
+ * not yet computed (long sweeps defer it). Persistent = the launch has fewer
+ * workgroups than tickets and every workgroup draws until none is left.
+ * Returns whether the workgroup shall draw again.
  */
+namespace detail {
 template <bool Upper, bool UnitDiag, int Vec, int PanelCols, int Depth,
-          int DeepDepth, typename ArType, bool Persistent = false,
-          typename MtxView, typename XView>
-__global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
-    MtxView mtx, XView x, std::uint32_t *helper, trsv_session session,
-    trsv_wide_split split)
+          int DeepDepth, typename ArType, bool Persistent, typename MtxView,
+          typename XView>
+__device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
+                                                 std::uint32_t *helper,
+                                                 trsv_session session,
+                                                 trsv_wide_split split)
 {
     using ar_type = decltype(mtx(0, 0) * x(0, 0));
     static_assert(std::is_same<ArType, ar_type>::value,
@@ -419,18 +423,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     const unsigned int total_tickets = static_cast<unsigned int>(split.tickets);
     const unsigned int last_event =
         Persistent ? total_tickets + gridDim.x - 1 : total_tickets - 1;
-    const int lane_of_thread = lane_id();
-    const int wave_of_thread = wave_id();
-    for (;;) {
-    // (made opaque once per ticket: what the body computes from the lane is
-    // invariant in this loop and would be computed - and kept - in front of it)
-    int lane_now = lane_of_thread;
-    int wave_now = wave_of_thread;
-    if constexpr (Persistent) {
-        asm volatile("" : "+v"(lane_now), "+v"(wave_now));
-    }
-    const int lane = lane_now;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave_now);
+    const int lane = lane_id();
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave_id());
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
     unsigned long long diag_stamp[20] = {};
     unsigned long long diag_poll_issue = 0;   // last probe issued by poll_finish
@@ -545,10 +539,10 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     };
     if (block == 0x3ffffffd) {
         finish();  // this workgroup's final draw
-        return;
+        return false;
     }
     if (block == 0x3fffffff) {
-        return;  // no ticket to be had: helper[0] says why
+        return false;  // no ticket to be had: helper[0] says why
     }
     if (block == detail::trsv_wide_prefetch_block) {
         detail::prefetch_ahead<Upper, R>(mtx_traits::data(mtx),
@@ -556,12 +550,7 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
                                          session.state, helper, shared_part,
                                          split.prefetchers);
         finish();
-        if constexpr (Persistent) {
-            __syncthreads();
-            continue;
-        } else {
-            return;
-        }
+        return Persistent;
     }
     const index_type base = block * R;
     // Split row blocks. A solve with more row blocks than CUs ends with the
@@ -1700,11 +1689,57 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
 #endif
 
     finish();
-    if constexpr (!Persistent) {
-        return;
+    return Persistent;
+}
+
+
+/** The same out of line: the row block's registers are allocated apart from
+ *  the ticket loop around it. Inlined into `for (;;)`, everything the body
+ *  derives from the lane index - a few hundred LDS and matrix addresses - is
+ *  invariant in that loop and was computed, and kept, in front of it: 256
+ *  registers and 670-780 bytes of scratch, solves 60-80 % slower
+ *  (profiles/r04_trsv_persistent.txt). Arguments of a device function travel
+ *  in vector registers; what is uniform is brought back into scalar ones. */
+template <bool Upper, bool UnitDiag, int Vec, int PanelCols, int Depth,
+          int DeepDepth, typename ArType, typename MtxView, typename XView>
+__device__ __noinline__ bool trsv_wide_ticket_call(MtxView mtx, XView x,
+                                                   std::uint32_t *helper,
+                                                   trsv_session session,
+                                                   trsv_wide_split split)
+{
+    return trsv_wide_ticket<Upper, UnitDiag, Vec, PanelCols, Depth, DeepDepth,
+                            ArType, true>(
+        wave_uniform(mtx), wave_uniform(x), wave_uniform(helper),
+        wave_uniform(session), wave_uniform(split));
+}
+}  // namespace detail
+
+
+/**
+ * Blocked triangular solve with 128-row blocks. blockDim = 512, grid = the
+ * solve's tickets (`trsv_wide_tickets`), or - Persistent - one workgroup per CU
+ * drawing tickets until none is left: row blocks beyond the CU count would
+ * otherwise wait for the hardware dispatcher, which binds workgroup k of a
+ * launch to XCD k mod 8 (see `kernel::trsv`).
+ */
+template <bool Upper, bool UnitDiag, int Vec, int PanelCols, int Depth,
+          int DeepDepth, typename ArType, bool Persistent = false,
+          typename MtxView, typename XView>
+__global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
+    MtxView mtx, XView x, std::uint32_t *helper, trsv_session session,
+    trsv_wide_split split)
+{
+    if constexpr (Persistent) {
+        while (detail::trsv_wide_ticket_call<Upper, UnitDiag, Vec, PanelCols,
+                                             Depth, DeepDepth, ArType>(
+            mtx, x, helper, session, split)) {
+            __syncthreads();  // the next ticket's work re-uses what lives in LDS
+        }
+    } else {
+        detail::trsv_wide_ticket<Upper, UnitDiag, Vec, PanelCols, Depth,
+                                 DeepDepth, ArType, false>(mtx, x, helper,
+                                                           session, split);
     }
-    __syncthreads();  // the next ticket's work re-uses what lives in LDS
-    }  // for (;;)
 }
 
 
@@ -1916,20 +1951,13 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
 #endif
     split.defer_from =
         (ACCBLAS_TRSV_WIDE_ALWAYS_DEFER == 0 && num_cus > 0) ? num_cus : 0;
-    // (the persistent form of THIS kernel is only built on request,
-    // -DACCBLAS_TRSV_WIDE_PERSISTENT: the loop around the row block costs it
-    // 170 spilled registers, profiles/r04_trsv_persistent.txt)
-#ifdef ACCBLAS_TRSV_WIDE_PERSISTENT
+    // (one workgroup per CU drawing tickets when there are more tickets than
+    // CUs; a launch with a workgroup for every ticket runs the loop-free kernel)
     const bool persistent = persistent_wanted && num_cus > 0 &&
                             tickets > static_cast<unsigned>(num_cus);
-#else
-    const bool persistent = false;
-    (void)persistent_wanted;
-#endif
     const dim3 grid(persistent ? static_cast<unsigned>(num_cus) : tickets);
     const dim3 block(trsv_wide_waves * wave_size);
     const unsigned pad = trsv_wide_single_block_pad<ArType>();
-#ifdef ACCBLAS_TRSV_WIDE_PERSISTENT
 #define ACCBLAS_TRSV_WIDE_LAUNCH(_upper, _unit)                                \
     if (persistent) {                                                          \
         kernel::trsv_wide<_upper, _unit, vec16, panel_cols, depth, deep_depth, \
@@ -1940,12 +1968,6 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
                           ArType, false>                                       \
             <<<grid, block, pad, stream>>>(mtx, x, helper, session, split);    \
     }
-#else
-#define ACCBLAS_TRSV_WIDE_LAUNCH(_upper, _unit)                                \
-    kernel::trsv_wide<_upper, _unit, vec16, panel_cols, depth, deep_depth,     \
-                      ArType, false>                                           \
-        <<<grid, block, pad, stream>>>(mtx, x, helper, session, split)
-#endif
     if (upper) {
         if (unit_diag) {
             ACCBLAS_TRSV_WIDE_LAUNCH(true, true);
@@ -1963,12 +1985,20 @@ hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
     return hipGetLastError();
 }
 
-/** Prefetching workgroups a solve gets (`trsv_wide_split::prefetchers`):
- *  the CUs the row blocks leave idle, up to 128 of them, where it was measured
- *  to pay - 4- and 8-byte storage, 32 to 144 row blocks (n = 4096 ... 18432),
- *  see `detail::prefetch_ahead`; with 2-byte storage, whose followers wait for
- *  the front and not for their tiles, they cost 5 %. `mode`: 0 never, 1 by
- *  that rule, 2 whenever CUs are idle (measurements). */
+/** Prefetching workgroups a solve gets (`trsv_wide_split::prefetchers`): the
+ *  CUs the row blocks leave idle, up to 128 of them, where it was measured to
+ *  pay. Round 3 (profiles/r03_trsv_prefetch.txt): 4-byte storage -3...-6 % and
+ *  8-byte storage -12...-26 % at 32 to 144 row blocks, 2-byte storage +5 %.
+ *  Round 5, re-measured under round 4's front loop (the followers' tile
+ *  requests now stay in flight across a hop, so a tile that waits in the
+ *  Infinity Cache buys nothing and its second trip through the fabric costs):
+ *  4-byte storage is 2-5 % SLOWER with prefetchers at n = 4096 ... 12288 and
+ *  8-25 % slower at 14336 ... 28000, both triangles, fp64 and fp32 arithmetic
+ *  (profiles/r05_trsv_prefetch_ab.txt) - the library's sweep had a 15 % cliff at
+ *  144 row blocks where the old rule switched them off. The rule is now 8-byte
+ *  storage only (which the library sends to the 64-row kernel unless option
+ *  "trsv_wide" = 2 asks for this one). `mode`: 0 never, 1 by that rule,
+ *  2 whenever CUs are idle (measurements). */
 template <typename StType>
 inline int trsv_wide_prefetchers_for(index_type n, int num_cus, int mode)
 {
@@ -1977,7 +2007,7 @@ inline int trsv_wide_prefetchers_for(index_type n, int num_cus, int mode)
     if (mode == 0 || spare <= 0) {
         return 0;
     }
-    if (mode == 1 && (sizeof(StType) < 4 || blocks < 32 || blocks > 144)) {
+    if (mode == 1 && (sizeof(StType) < 8 || blocks < 32 || blocks > 144)) {
         return 0;
     }
     return spare < 128 ? spare : 128;

@@ -26,6 +26,25 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (wave_size - 1);
 /** Wave index inside a 1-D workgroup. */
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+/** `value` (the same in every lane) as scalar registers: lane 0's copy, word
+ *  by word. Arguments of an out-of-line device function arrive in vector
+ *  registers whatever they hold; what is computed from them would stay there. */
+template <typename T>
+__device__ __forceinline__ T wave_uniform(const T &value)
+{
+    static_assert(sizeof(T) % 4 == 0 && std::is_trivially_copyable<T>::value,
+                  "whole 32-bit words");
+    std::uint32_t words[sizeof(T) / 4];
+    __builtin_memcpy(words, &value, sizeof(T));
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) {
+        words[i] = __builtin_amdgcn_readfirstlane(words[i]);
+    }
+    T out = value;  // (T need not be default-constructible)
+    __builtin_memcpy(&out, words, sizeof(T));
+    return out;
+}
+
 
 /**
  * All-reduce over `width` consecutive lanes (power of two, <= 64) with a
@@ -67,7 +86,7 @@ __device__ __forceinline__ T dpp_move(T value)
     for (unsigned i = 0; i < sizeof(T) / 4; ++i) {
         words[i] = __builtin_amdgcn_update_dpp(0, words[i], Ctrl, 0xF, 0xF, true);
     }
-    T out;
+    T out = value;  // (T need not be default-constructible)
     __builtin_memcpy(&out, words, sizeof(T));
     return out;
 }

@@ -120,13 +120,20 @@ size_t accblas_dtype_size(accblas_dtype t);
  *                 columns, the owner adds their sums in a fixed order);
  *                 0 (default) = that rule, k > 0 = from row block k on (at
  *                 least 98).
- *   "trsv_prefetch"  128-row kernel: 1 (default) = solves of 4- or 8-byte
- *                 storage with 32 to 144 row blocks (n = 4096 ... 18432) launch extra
- *                 workgroups on the CUs the row blocks leave idle, which pull
- *                 the tiles of the next block columns into the Infinity Cache
- *                 ahead of the chain's front (4-byte storage 3-6 % faster,
- *                 8-byte 12-26 %; same bits);
+ *   "trsv_prefetch"  128-row kernel: 1 (default) = solves of 8-byte storage
+ *                 with 32 to 144 row blocks (n = 4096 ... 18432; reached with
+ *                 "trsv_wide" = 2 only) launch extra workgroups on the CUs the
+ *                 row blocks leave idle, which pull the tiles of the next block
+ *                 columns into the Infinity Cache ahead of the chain's front
+ *                 (12-26 % faster; same bits). 4-byte storage no longer: under
+ *                 the front loop it is 2-25 % slower with them;
  *                 0 = never; 2 = whenever CUs are idle.
+ *   "trsv_wide_persistent"  128-row kernel, solves with more tickets (row
+ *                 blocks + helpers' shares) than CUs: 1 = one workgroup per CU
+ *                 draws tickets until none is left (the hardware dispatcher
+ *                 binds workgroup k of a launch to XCD k mod 8: with a
+ *                 workgroup per ticket the last tickets start when a CU of
+ *                 THEIR XCD frees up); 0 = one workgroup per ticket. Same bits.
  * Unknown names and other values return ACCBLAS_ERR_INVALID_ARGUMENT. */
 int accblas_set_option(const char *name, int value);
 
