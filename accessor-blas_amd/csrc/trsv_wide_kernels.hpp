@@ -43,74 +43,11 @@
 #include <hip/hip_runtime.h>
 
 #include "trsv_kernels.hpp"
+#include "trsv_wide_detail.hpp"
 
 
 namespace accblas {
 namespace dev {
-
-
-constexpr int trsv_wide_rows = 128;
-constexpr int trsv_wide_waves = 8;
-
-/** Block columns next to its diagonal that a workgroup with a long far sweep
- *  keeps for after the panel fold (see `defer_fold` in the kernel). */
-#ifndef ACCBLAS_TRSV_WIDE_DEFERRED
-#define ACCBLAS_TRSV_WIDE_DEFERRED 48
-#endif
-constexpr index_type trsv_wide_deferred_columns = ACCBLAS_TRSV_WIDE_DEFERRED;
-
-/** The virtual unknowns in front of an upper solve (`trsv_virtual_pad`). */
-template <typename StType>
-constexpr index_type trsv_wide_virtual_pad(bool upper, index_type n)
-{
-    return trsv_virtual_pad<StType>(upper, n);
-}
-
-/** Row blocks from `first_block` on are worked on by `parts` workgroups each
- *  (see `kernel::trsv_wide`); parts == 1 switches the splitting off. */
-struct trsv_wide_split {
-    int first_block;
-    int parts;
-    int tail_block;  // blocks from here on have `tail_parts` workgroups each
-    int tail_parts;  // (smaller shares: the last tickets run almost alone)
-    int tail_deferred;  // block columns the owner of a tail block keeps
-    int last_block;  // blocks from here on (>= tail_block): `last_parts` each,
-    int last_parts;  // their owners keep `tail_deferred` columns as well
-    // Workgroups beyond the ones that solve (the last tickets): they run on
-    // CUs the solve leaves idle and pull the tiles of the next block columns
-    // into the Infinity Cache ahead of the chain's front (see
-    // `detail::prefetch_ahead`)
-    int prefetchers;
-    // Tickets of the solve (solving workgroups + prefetchers): what
-    // `trsv_wide_grid` returns. A launch may have fewer workgroups than
-    // tickets (one per CU): they draw tickets until none is left.
-    int tickets;
-    // Row blocks from this one on fold their panel late when their far sweep
-    // is long (see `defer_fold` in the kernel): the row blocks that START late.
-    // The ones that have a CU from the first moment of the solve (set by the
-    // launcher: all of them, or the first `num_cus`) fold at once, while the
-    // chain is still far away.
-    int defer_from;
-};
-constexpr int trsv_wide_max_parts = trsv_partial_slots + 1;
-// helpers' sums an owner takes through LDS at a time
-constexpr int trsv_wide_join_slots = 7;
-
-/** Granule words of the partial-sum area that follows the x granules in the
- *  workspace: (parts - 1) x 128 partial sums per row block, one or two words
- *  each (arithmetic type), tagged like the x granules. Sized for fp64
- *  arithmetic and the maximum number of parts. */
-constexpr index_type trsv_wide_partial_words(index_type n)
-{
-    return ceildiv(n, index_type{trsv_wide_rows}) * (trsv_wide_max_parts - 1) *
-           trsv_wide_rows * 2;
-}
-
-/** First word of that area (64-word aligned behind n x words_per_element). */
-constexpr index_type trsv_wide_partial_offset(index_type n, int words_per_element)
-{
-    return ceildiv(n * words_per_element, index_type{64}) * 64;
-}
 
 
 // Diagnostic builds only (tools/tune_trsv_wide.hip defines
@@ -119,231 +56,27 @@ constexpr index_type trsv_wide_partial_offset(index_type n, int words_per_elemen
 // stamps cost no memory traffic while the block is on the chain. The library
 // is never built with it.
 #ifdef ACCBLAS_TRSV_WIDE_DIAG
+constexpr bool trsv_wide_diag = true;
 __device__ unsigned long long *trsv_wide_diag_buffer;
 // one record per workgroup, (block * trsv_wide_max_parts + part) * 8 words: start, sweep start,
 // first time at the front, block column then, end, first column, end column
 __device__ unsigned long long *trsv_wide_diag_workgroups;
-#define ACCBLAS_TRSV_WIDE_STAMP(_slot) diag_stamp[_slot] = wall_clock64()
 #else
-#define ACCBLAS_TRSV_WIDE_STAMP(_slot) \
-    do {                               \
-    } while (false)
+constexpr bool trsv_wide_diag = false;
+constexpr unsigned long long *trsv_wide_diag_buffer = nullptr;
+constexpr unsigned long long *trsv_wide_diag_workgroups = nullptr;
 #endif
+// (the stamps live in `diag_stamp`, an array of the kernel body that no code is
+// generated for unless `trsv_wide_diag`)
+#define ACCBLAS_TRSV_WIDE_STAMP(_slot)          \
+    do {                                        \
+        if constexpr (trsv_wide_diag) {         \
+            diag_stamp[_slot] = wall_clock64(); \
+        }                                       \
+    } while (false)
 
 
 namespace kernel {
-namespace detail {
-
-
-/** Block columns a prefetching workgroup keeps ahead of the chain's front. */
-constexpr int trsv_wide_prefetch_ahead = 5;
-/** What a prefetching workgroup finds in place of a row block. */
-constexpr std::int32_t trsv_wide_prefetch_block = 0x3ffffffe;
-
-/**
- * The life of a prefetching workgroup (`trsv_wide_split::prefetchers`): it
- * follows `trsv_state::front` and touches every cache line of the tiles
- * (row block b, block column c) for c up to `trsv_wide_prefetch_ahead` columns
- * beyond the front and b = c + 1 + index, c + 1 + index + count, ... - one
- * 4-byte load per 128-byte line and thread, the values are thrown away. Why:
- * a follower's turn-around per block column is the latency of its own tile
- * (the compiler's loop over the register ring waits for the tile it has just
- * issued, see profiles/r03_trsv_hop_paths.txt), every block is a follower
- * until its turn, and a tile that waits in the Infinity Cache arrives sooner
- * than one that comes from HBM. Measured as a kernel of its own beside the
- * solve (tools/tune_trsv_prefetch.hip, profiles/r03_trsv_prefetch.txt, 4-byte
- * storage): n = 6144 -6 %, 8192 -5 %, 12288 -6 %, 16384 -4.5 %, 18432 -2.5 %,
- * 20480 +1.5 %, 24000 +4.7 % (there the second copy of 12 MB per hop is more
- * than the fabric has to spare); as workgroups of the solve itself (library
- * builds alternated in one process): 4096 -3.9 %, 6144 -6.2 %, 12288 -5 %,
- * 16384 -2.5 %; 8-byte storage 4096 -15 %, 8192 -26 %, 16384 -12 % (its
- * tiles are twice as large); 2-byte storage +5 % (not used there). Returns when the front is within three block
- * columns of the end, when a solver workgroup has given up, or after
- * `trsv_spin_limit` looks at a front that has not moved meanwhile; it never
- * writes the error word itself.
- */
-template <bool Upper, int R, typename StType>
-__device__ __forceinline__ void prefetch_ahead(const StType *a_data,
-                                               index_type lda, index_type n,
-                                               const trsv_state *state,
-                                               std::uint32_t *helper,
-                                               int index, int count)
-{
-    constexpr int line_elements = 128 / static_cast<int>(sizeof(StType));
-    constexpr int lines_per_row = R / line_elements;  // of one tile row
-    constexpr int lines = R * lines_per_row;          // of one tile
-    const int blocks = static_cast<int>(ceildiv(n, index_type{R}));
-    int done = 2;  // block columns below this are taken care of
-    unsigned int spins = 0;
-    int last_front = -1;
-    std::uint32_t bits = 0;
-    while (true) {
-        const int front = static_cast<int>(
-            __hip_atomic_load(&state->front, __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_AGENT));
-        if (front + 3 >= blocks) {
-            break;
-        }
-        const int upto = front + 1 + trsv_wide_prefetch_ahead < blocks - 1
-                             ? front + 1 + trsv_wide_prefetch_ahead
-                             : blocks - 1;
-        done = done < front + 1 ? front + 1 : done;  // (what the front has passed)
-        if (front != last_front) {
-            last_front = front;
-            spins = 0;  // the limit is on a front that does not MOVE
-        }
-        if (done >= upto) {
-            // A prefetcher is optional: it leaves when a solver has given up
-            // or when the front has stood still for `trsv_spin_limit` looks,
-            // but it never declares the solve failed (a solve stretched by
-            // other streams' kernels completes without it).
-            ++spins;
-            if (spins >= trsv_spin_limit ||
-                ((spins & 1023u) == 0 &&
-                 __hip_atomic_load(helper, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT) ==
-                     trsv_error_word)) {
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-            continue;
-        }
-        for (int c = done; c < upto; ++c) {
-            for (int b = c + 1 + index; b < blocks; b += count) {
-                for (int line = static_cast<int>(threadIdx.x); line < lines;
-                     line += static_cast<int>(blockDim.x)) {
-                    const index_type row =
-                        index_type{b} * R + line / lines_per_row;
-                    const index_type col = index_type{c} * R +
-                                           (line % lines_per_row) * line_elements;
-                    if (row < n) {
-                        const index_type mem_row = Upper ? n - 1 - row : row;
-                        const index_type mem_col =
-                            Upper ? n - 1 - (col + line_elements - 1) : col;
-                        StType value = a_data[mem_row * lda +
-                                              (mem_col > 0 ? mem_col : 0)];
-                        std::uint32_t word = 0;
-                        __builtin_memcpy(&word, &value,
-                                         sizeof(StType) < 4 ? sizeof(StType) : 4);
-                        bits ^= word;
-                    }
-                }
-            }
-        }
-        done = upto;
-    }
-    if (bits == 0x5a17c0deu && spins == 0x7fffffffu) {
-        helper[1] = bits;  // never: keeps the loads alive
-    }
-}
-
-
-/** Where element `within` (0..15) of a 16-wide row of an MFMA result tile
- *  lives: lane group `quad` (lane >> 4) and accumulator register `reg`, the
- *  inverse of `mma_16x16x4<T>::row`. */
-template <typename T>
-struct mma_slot;
-
-template <>
-struct mma_slot<double> {
-    __device__ __forceinline__ static int quad(int within) { return within & 3; }
-    __device__ __forceinline__ static int reg(int within) { return within >> 2; }
-};
-
-template <>
-struct mma_slot<float> {
-    __device__ __forceinline__ static int quad(int within) { return within >> 2; }
-    __device__ __forceinline__ static int reg(int within) { return within & 3; }
-};
-
-
-/** Sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (all four end with it). */
-template <typename T>
-__device__ __forceinline__ T quad_column_sum(T value)
-{
-    // (value + the lane 16 away, then + the lane 32 away, as two
-    // `__shfl_xor` steps would give - without their trips through LDS: this
-    // sum ends both c and W x on the chain's hop)
-    value = lane_bit_pair_sum<4>(value);
-    return lane_bit_pair_sum<5>(value);
-}
-
-
-/**
- * This lane's share of c = inv(T) rhs for a row of row tile `Tile` (rows
- * 16 Tile .. 16 Tile + 15 of the 128-row block; `row` = this lane's row inside
- * the block). The row's columns k < 16 (Tile + 1) are split over its four
- * lanes in runs of eight: lane group fk takes k = 32 m + 8 fk + j, j < 8.
- *   * Eight columns apart, the four lanes of a row - and with them the 64
- *     lanes of the wave, whose rows are consecutive - fall on bank pairs
- *     (8 fk + fi) mod 32, every pair exactly twice: the minimum for 64 8-byte
- *     reads. With neighbouring columns per lane (k = 16 s + 4 q + fk, the
- *     layout until round 3) the pairs were (fk + fi) mod 32, up to four lanes
- *     each, and the eight waves' reads queued in the one LDS: 0.64 us between
- *     "all far sums in LDS" and "c ready" for the slowest wave, on the chain's
- *     two-hop path x_{b-2} -> c -> x_b (profiles/r03_trsv_hop_paths.txt).
- *   * The trip count is a compile-time constant: every LDS read of the row is
- *     issued before the first FMA needs one.
- * `x00`, `x11`, `x10` = the inverse's three 64 x 64 tiles, column-major with
- * leading dimension `ld`. Four partial sums per lane (j mod 4), ascending k.
- */
-template <int Tile, int ld, typename T>
-__device__ __forceinline__ T inverse_row_times(const T *x00, const T *x11,
-                                               const T *x10, const T *rhs,
-                                               int row, int fk)
-{
-    constexpr int H = 64;
-    constexpr int columns = 16 * (Tile + 1);
-    constexpr int runs = (columns + 31) / 32;
-    // (two runs - 16 entries and 16 right-hand sides, 64 registers with fp64 -
-    // are read ahead of their FMAs at a time: all four at once made this the
-    // place where the kernel needs the most registers, and what is live across
-    // it - W, the row pointers of the sweep - paid for that with spills)
-    constexpr int batch = 2;
-    T part[4] = {};
-#pragma unroll
-    for (int m0 = 0; m0 < runs; m0 += batch) {
-        T entry[batch][8];
-        T right[batch][8];
-#pragma unroll
-        for (int mb = 0; mb < batch; ++mb) {
-            const int m = m0 + mb;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 32 * m + 8 * fk + j;
-                // (columns beyond the row's last tile exist in LDS - the same
-                // 64-column tile - and are masked out)
-                T value{};
-                if (m < runs) {
-                    if (Tile < 4) {
-                        value = x00[k * ld + row];
-                    } else if (32 * m < H) {
-                        value = x10[k * ld + row - H];
-                    } else {
-                        value = x11[(k - H) * ld + row - H];
-                    }
-                }
-                entry[mb][j] =
-                    (m < runs && (32 * m + 31 < columns || k < columns)) ? value
-                                                                          : T{};
-                right[mb][j] = m < runs ? rhs[k] : T{};
-            }
-        }
-#pragma unroll
-        for (int mb = 0; mb < batch; ++mb) {
-            if (m0 + mb < runs) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    part[j & 3] += entry[mb][j] * right[mb][j];
-                }
-            }
-        }
-    }
-    return (part[0] + part[1]) + (part[2] + part[3]);
-}
-
-
-}  // namespace detail
 
 
 /**
@@ -362,12 +95,17 @@ namespace detail {
 template <bool Upper, bool UnitDiag, int Vec, int PanelCols, int Depth,
           int DeepDepth, typename ArType, bool Persistent, typename MtxView,
           typename XView>
-__device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
-                                                 std::uint32_t *helper,
-                                                 trsv_session session,
-                                                 trsv_wide_split split)
+__device__ __forceinline__ bool trsv_wide_ticket(
+    index_type unknowns, index_type lda, index_type x_inc,
+    const std::remove_cv_t<typename view_traits<XView>::storage_type> *a_data,
+    std::remove_cv_t<typename view_traits<XView>::storage_type> *x_data,
+    std::uint32_t *helper, trsv_session session, trsv_wide_split split)
 {
-    using ar_type = decltype(mtx(0, 0) * x(0, 0));
+    // (the views' contents arrive unpacked - `unknowns` = mtx.length(0), row
+    // stride, increment, data pointers -: the out-of-line copy of this function
+    // then has few enough arguments to get all of them in registers)
+    using ar_type = decltype((*static_cast<const MtxView *>(nullptr))(0, 0) *
+                             (*static_cast<const XView *>(nullptr))(0, 0));
     static_assert(std::is_same<ArType, ar_type>::value,
                   "accessor arithmetic must yield ArType");
     using mtx_traits = view_traits<MtxView>;
@@ -425,11 +163,9 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
         Persistent ? total_tickets + gridDim.x - 1 : total_tickets - 1;
     const int lane = lane_id();
     const int wave_u = __builtin_amdgcn_readfirstlane(wave_id());
-#ifdef ACCBLAS_TRSV_WIDE_DIAG
     unsigned long long diag_stamp[20] = {};
     unsigned long long diag_poll_issue = 0;   // last probe issued by poll_finish
     unsigned long long diag_poll_probes = 0;  // probes issued by poll_finish
-#endif
     ACCBLAS_TRSV_WIDE_STAMP(0);  // kernel entry
     const int fi = lane & 15;  // MFMA fragment row (A) / column (B, D)
     const int fk = lane >> 4;  // MFMA fragment k / lane group of a W row
@@ -437,8 +173,8 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
     // in front, see `trsv_wide_virtual_pad`); logical index l exists if
     // pad <= l < n
     const index_type pad =
-        trsv_wide_virtual_pad<st_type>(Upper, mtx.length(0));
-    const index_type n = mtx.length(0) + pad;
+        trsv_wide_virtual_pad<st_type>(Upper, unknowns);
+    const index_type n = unknowns + pad;
     const auto exists = [pad, n](index_type logical) {
         return logical >= pad && logical < n;
     };
@@ -545,8 +281,8 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
         return false;  // no ticket to be had: helper[0] says why
     }
     if (block == detail::trsv_wide_prefetch_block) {
-        detail::prefetch_ahead<Upper, R>(mtx_traits::data(mtx),
-                                         mtx_traits::stride(mtx), n,
+        detail::prefetch_ahead<Upper, R>(a_data,
+                                         lda, n,
                                          session.state, helper, shared_part,
                                          split.prefetchers);
         finish();
@@ -579,10 +315,6 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
     const auto phys = [n](index_type logical) {
         return Upper ? n - 1 - logical : logical;
     };
-    const st_type *a_data = mtx_traits::data(mtx);
-    const index_type lda = mtx_traits::stride(mtx);
-    st_type *x_data = x_traits::data(x);
-    const index_type x_inc = x_traits::stride(x);
 
     // this block's right-hand side (never written by another workgroup):
     // loaded ahead of the tiles, used behind them, one wait for all
@@ -645,24 +377,10 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
     __syncthreads();
     ACCBLAS_TRSV_WIDE_STAMP(13);  // tiles staged
 
-    // EXPERIMENT, off (ACCBLAS_TRSV_WIDE_DIRECT = number of such blocks): the
-    // first row blocks do not invert - they keep the staged triangle and solve
-    // by substitution at their turn (see "direct row blocks" below). Block 0
-    // then publishes 9.6 us after the launch instead of 14.9 (n = 8192), but a
-    // direct hop takes 5 us (two 64-row substitutions + a mat-vec by one wave)
-    // against 2.4 us with the inverse, and the first block with a FOLDED panel
-    // publishes at 35-36 us either way: all folds finish 24 us after the launch
-    // (12 us of matrix-core time per block) and the block then has its far
-    // columns to catch up on. Same solve times (profiles/r04_trsv_wide_start.txt).
-#ifndef ACCBLAS_TRSV_WIDE_DIRECT
-#define ACCBLAS_TRSV_WIDE_DIRECT 0
-#endif
-    constexpr index_type direct_blocks = ACCBLAS_TRSV_WIDE_DIRECT;
-    const bool direct_block = block < direct_blocks;
     // ---- invert D00 (even waves) and D11 (odd waves) at the same time -------
     // (the serial 16 x 16 substitutions run on team wave 0 = waves 0 and 1,
     // which sit on different SIMDs)
-    if (!helper_part && !direct_block) {
+    if (!helper_part) {
         const int team = wave_u % 2;
         ar_type *scratch = tiles[3] + team * 1024;
         detail::invert_tile64<UnitDiag>(tiles[team], scratch, scratch + 512,
@@ -673,7 +391,7 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
     ACCBLAS_TRSV_WIDE_STAMP(14);  // diagonal tiles inverted
 
     // ---- X10 = -X11 (D10 X00): 16 output tiles, two per wave ---------------
-    if (!helper_part && !direct_block) {
+    if (!helper_part) {
         const int tj = wave_u % 4;
         const int ti_of[2] = {wave_u / 4, 3 - wave_u / 4};
         typename mma::acc_type y[2];
@@ -825,12 +543,7 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
     // chain stood still from 26.6 to 35 us, when block 6 had folded AND caught
     // up on its far columns; eight: -1...-6 % at n = 4096 ... 8192, -1...-2 % at
     // 24000, eleven and fourteen no better (profiles/r04_trsv_wide_start.txt).
-#ifndef ACCBLAS_TRSV_WIDE_UNFOLDED
-#define ACCBLAS_TRSV_WIDE_UNFOLDED 8
-#endif
-    constexpr index_type unfolded_blocks = ACCBLAS_TRSV_WIDE_UNFOLDED;
-    static_assert(direct_blocks <= unfolded_blocks,
-                  "a direct row block treats x_{b-1} as a far column");
+    constexpr index_type unfolded_blocks = 8;
     const bool folded = block >= unfolded_blocks;
     if (folded && !defer_fold && !helper_part) {
         fold_panel();
@@ -860,10 +573,10 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
         }
         while (!__all(io::ready(raw0, epoch) && io::ready(raw1, epoch)) &&
                !detail::spin_expired(spins, helper)) {
-#ifdef ACCBLAS_TRSV_WIDE_DIAG
-            diag_poll_issue = wall_clock64();  // issue time of this probe
-            ++diag_poll_probes;
-#endif
+            if constexpr (trsv_wide_diag) {
+                diag_poll_issue = wall_clock64();  // issue time of this probe
+                ++diag_poll_probes;
+            }
             io::load(granules, first, raw0);
             io::load(granules, first + H, raw1);
         }
@@ -1054,12 +767,12 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
             }
             lds_barrier();
         } else {
-#ifdef ACCBLAS_TRSV_WIDE_DIAG
-            if (diag_stamp[16] == 0) {
-                diag_stamp[16] = wall_clock64();
-                diag_stamp[17] = static_cast<unsigned long long>(column);
+            if constexpr (trsv_wide_diag) {
+                if (diag_stamp[16] == 0) {
+                    diag_stamp[16] = wall_clock64();
+                    diag_stamp[17] = static_cast<unsigned long long>(column);
+                }
             }
-#endif
             at_front = true;  // from now on the columns come one at a time
         }
         chunk_first = column;
@@ -1124,16 +837,13 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
     // chain's front (what the ring holds beyond it is dropped: the front loop
     // below requests it again).
     // Whole rounds of the ring whose refills all exist run WITHOUT a condition
-    // around the refill (`ACCBLAS_TRSV_WIDE_PLAIN_SWEEP`): behind `if (cb + D <
+    // around the refill: behind `if (cb + D <
     // end)` a slot is a phi of "loaded" and "kept", and the compiler loaded
     // into spare registers and copied them into the slot behind `s_waitcnt
     // vmcnt(7) ... vmcnt(0)` - right behind the step's FMAs, i.e. every step
     // waited for the tile it had just requested and the ring was one step deep
     // in time whatever its depth (the deferred sweep of a late row block, four
     // steps on paper: profiles/r04_trsv_wide_sweep_ring.txt).
-#ifndef ACCBLAS_TRSV_WIDE_PLAIN_SWEEP
-#define ACCBLAS_TRSV_WIDE_PLAIN_SWEEP 1
-#endif
     const auto sweep = [&](auto depth_tag, auto until_front_tag,
                            index_type begin, index_type end) -> index_type {
         constexpr int D = decltype(depth_tag)::value;
@@ -1151,8 +861,7 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
         // as well the lower instantiations spill 56 bytes and lose 5-12 %)
         // (4-byte storage: n = 36000 ... 49152 -1 ... -6 % depending on the box,
         // 65536 unchanged; 2-byte storage loses 3-5 % with it)
-        if (ACCBLAS_TRSV_WIDE_PLAIN_SWEEP != 0 && D > Depth &&
-            sizeof(st_type) == 4) {
+        if (D > Depth && sizeof(st_type) == 4) {
             for (; cb0 + 2 * D <= end; cb0 += D) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
@@ -1232,9 +941,6 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
             x_chunk[H + lane] = io::decode(probe1);
             // this wave's share of the tile `Depth - 1` columns ahead, into
             // the slot of the column consumed one step ago
-#ifndef ACCBLAS_TRSV_WIDE_DEFERRED_REFILL
-#define ACCBLAS_TRSV_WIDE_DEFERRED_REFILL 1
-#endif
             // (`refill`: a literal `true` in the main loop below, where the
             // step exists - the request is then unconditional and lands in the
             // slot's own registers. Behind a condition the slot is a phi of
@@ -1247,30 +953,20 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
             // branches around the loads, no copies, and without the condition
             // the upper instantiations spill - n = 24000: 335 -> 547 us)
             constexpr bool plain_refill = sizeof(ar_type) < 8;
-            if (ACCBLAS_TRSV_WIDE_DEFERRED_REFILL != 0 &&
-                (plain_refill ? (refill || c - 1 + Depth < far_end)
-                              : (c >= 1 && c - 1 + Depth < far_end))) {
+            if (plain_refill ? (refill || c - 1 + Depth < far_end)
+                             : (c >= 1 && c - 1 + Depth < far_end)) {
                 issue(c - 1 + Depth, previous);
             }
         }
         lds_barrier();
         apply(c, slot, col_group * Vec);
-#ifndef ACCBLAS_TRSV_WIDE_TOUCH
-#define ACCBLAS_TRSV_WIDE_TOUCH 1
-#endif
         if constexpr (Poller) {
             if (c + 1 < far_end) {
                 poll_begin((c + 1) * R + lane, probe0, probe1);
                 probe_pending = true;
             }
-            if (ACCBLAS_TRSV_WIDE_DEFERRED_REFILL == 0 && refill) {
-                // (experiment: the poller refills like everybody else, behind
-                // its early probe)
-                issue(c + Depth, slot);
-            }
         } else {
-            if (ACCBLAS_TRSV_WIDE_TOUCH != 0 && wave_u == 1 &&
-                c + Depth < far_end) {
+            if (wave_u == 1 && c + Depth < far_end) {
                 // wave 0's rows of the tile it will ask for one hop from now:
                 // one 4-byte load per 128-byte line (default cache policy)
                 constexpr int line_elements = 128 / static_cast<int>(sizeof(st_type));
@@ -1309,8 +1005,7 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
             // (the poller's share of step begin + D - 1 is requested by its
             // first step, as of every later one)
             if (begin + d < end &&
-                !(ACCBLAS_TRSV_WIDE_DEFERRED_REFILL != 0 && Poller &&
-                  d == D - 1 && (sizeof(ar_type) < 8 || begin >= 1))) {
+                !(Poller && d == D - 1 && (sizeof(ar_type) < 8 || begin >= 1))) {
                 issue(begin + d, ring[d]);
             }
         }
@@ -1464,26 +1159,16 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
         probe_pending = false;
     }
     if (far_end > swept) {
-        // 0 = never, 1 = 4-byte storage (default), 2 = every storage type.
-        // Measured (profiles/r04_trsv_wide_front.txt): with the front loop AND
-        // without deferred folds an upper solve of 4-byte storage takes 273
-        // instead of 324 us at n = 20000, 333 instead of 390 at 24000, 508
-        // instead of 549 at 32768 (equal up to 16384). The lower instantiation
-        // gained nothing and lost 15-18 % at 8192-16384 as long as it spilled
-        // (60 bytes of row addresses, reloaded on the two-hop path behind the
-        // tile loads in flight); with the addresses formed where they are used
-        // (`row_ptr`) it is equal up to 16384 and takes 333 instead of 382 us
-        // at 24000, 505 instead of 532 at 32768 (section 5 of that profile).
-#ifndef ACCBLAS_TRSV_WIDE_FRONT_LOOP
-#define ACCBLAS_TRSV_WIDE_FRONT_LOOP 1
-#endif
-        // (2-byte storage: 129 -> 209 us at n = 8192 upper, 324 -> 348 at 24000
-        // lower with it; its ring is three deep and its tiles half as large -
-        // not looked into)
-        if constexpr ((ACCBLAS_TRSV_WIDE_FRONT_LOOP == 2 ||
-                       (ACCBLAS_TRSV_WIDE_FRONT_LOOP == 1 &&
-                        sizeof(st_type) == 4)) &&
-                      PPB == 1) {
+        // 4-byte storage only. Measured (profiles/r04_trsv_wide_front.txt): with
+        // the front loop AND without deferred folds an upper solve of 4-byte
+        // storage takes 273 instead of 324 us at n = 20000, 333 instead of 390
+        // at 24000, 508 instead of 549 at 32768 (equal up to 16384); the lower
+        // instantiation the same once its row addresses were formed where
+        // they are used (`row_ptr`). 2-byte storage is equal at 8192 and 4-12 %
+        // SLOWER from 16384 on with it, whatever its ring's depth
+        // (profiles/r05_trsv_f16_front.txt: its general sweep already runs at
+        // the hop 4-byte storage needs this loop for).
+        if constexpr (sizeof(st_type) == 4 && PPB == 1) {
             // catch up with what is published in chunks, then follow the front
             swept = sweep(std::integral_constant<int, Depth>{}, std::true_type{},
                           swept, far_end);
@@ -1515,57 +1200,6 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
     lds_barrier();  // (what is handed over lives in LDS)
     ACCBLAS_TRSV_WIDE_STAMP(4);  // every wave's far sums in LDS
 
-    if (direct_block) {
-        // ---- direct row blocks: substitution instead of an inverse ----------
-        // rhs_lds holds this block's right-hand side minus ALL earlier columns
-        // (x_{b-1} was swept like any far column). Wave 0 alone, no barrier:
-        // x_top = T00 \ rhs_top in the wave (lane = row), r = rhs_bottom -
-        // T10 x_top (lane = row, x_top broadcast from LDS), x_bottom = T11 \ r.
-        // The triangle lies in LDS as staged: row-major, zeros above the
-        // diagonal, identity rows where the matrix ends.
-        if (wave_u == 0) {
-            const ar_type *t00 = tiles[0], *t11 = tiles[1], *t10 = tiles[2];
-            ar_type inv_top{1}, inv_bottom{1};
-            if (!UnitDiag) {
-                inv_top = ar_type{1} / t00[lane * ld + lane];
-                inv_bottom = ar_type{1} / t11[lane * ld + lane];
-            }
-            const index_type left = n - base;  // rows of the block that exist
-            const int rows_top = left < H ? static_cast<int>(left) : H;
-            const int rows_bottom =
-                left <= H ? 0 : (left - H < H ? static_cast<int>(left - H) : H);
-            const ar_type x_top = detail::substitute_tile64<UnitDiag>(
-                t00, ld, 1, rhs_lds[lane], inv_top, lane, rows_top);
-            own_lds[lane] = x_top;  // (own_lds went into rhs_lds: free)
-            lds_release();
-            lds_acquire();
-            ar_type part[4] = {};
-#pragma unroll
-            for (int j = 0; j < H; ++j) {
-                part[j & 3] += t10[lane * ld + j] * own_lds[j];
-            }
-            const ar_type r_bottom =
-                rhs_lds[H + lane] - ((part[0] + part[1]) + (part[2] + part[3]));
-            ACCBLAS_TRSV_WIDE_STAMP(5);
-            const ar_type x_bottom = detail::substitute_tile64<UnitDiag>(
-                t11, ld, 1, r_bottom, inv_bottom, lane, rows_bottom);
-            const ar_type halves[2] = {x_top, x_bottom};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const index_type own_row = base + h * H + lane;
-                if (own_row < n) {
-                    // (virtual unknowns of an upper solve: handed on - x = 0
-                    // -, not stored)
-                    const st_type solution = static_cast<st_type>(halves[h]);
-                    io::publish(granules, own_row, solution, epoch);
-                    if (own_row >= pad) {
-                        x_data[phys(own_row) * x_inc] = solution;
-                    }
-                }
-            }
-            ACCBLAS_TRSV_WIDE_STAMP(9);  // published
-        }
-    } else {
     // the poller's first probe for x_{b-1} travels while c is computed
     granule_word tail_raw0[io::words];
     granule_word tail_raw1[io::words];
@@ -1608,15 +1242,15 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
             // hands them over through LDS as stored (the lanes widen them),
             // already in the lanes' read order: element 16 tj + within goes
             // to lane group quad(within), position 4 tj + reg(within)
-#ifdef ACCBLAS_TRSV_WIDE_DIAG
-            diag_poll_probes = 0;
-            diag_poll_issue = 0;
-#endif
+            if constexpr (trsv_wide_diag) {
+                diag_poll_probes = 0;
+                diag_poll_issue = 0;
+            }
             poll_finish(base - R + lane, tail_raw0, tail_raw1);
-#ifdef ACCBLAS_TRSV_WIDE_DIAG
-            diag_stamp[18] = diag_poll_probes;  // probes of the hop's own wait
-            diag_stamp[19] = diag_poll_issue;   // issue time of the one that saw it
-#endif
+            if constexpr (trsv_wide_diag) {
+                diag_stamp[18] = diag_poll_probes;  // probes of the hop's own wait
+                diag_stamp[19] = diag_poll_issue;   // issue time of the one that saw it
+            }
             if (lane == 0) {
                 // blocks 0 .. b-1 are published and visible (just read from
                 // memory): tell the workgroups far behind the front
@@ -1664,29 +1298,28 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
         }
     }
     ACCBLAS_TRSV_WIDE_STAMP(9);  // published
-    }  // block with an inverse
     }  // owner
-#ifdef ACCBLAS_TRSV_WIDE_DIAG
-    if (lane == 0 && trsv_wide_diag_buffer != nullptr && !helper_part) {
-        for (int i = 0; i < 20; ++i) {
-            trsv_wide_diag_buffer[(block * Waves + wave_u) * 20 + i] =
-                diag_stamp[i];
+    if constexpr (trsv_wide_diag) {
+        if (lane == 0 && trsv_wide_diag_buffer != nullptr && !helper_part) {
+            for (int i = 0; i < 20; ++i) {
+                trsv_wide_diag_buffer[(block * Waves + wave_u) * 20 + i] =
+                    diag_stamp[i];
+            }
+        }
+        if (threadIdx.x == 0 && trsv_wide_diag_workgroups != nullptr) {
+            unsigned long long *record =
+                trsv_wide_diag_workgroups +
+                (block * trsv_wide_max_parts + part) * 8;
+            record[0] = diag_stamp[0];
+            record[1] = helper_part ? diag_stamp[12] : diag_stamp[1];
+            record[2] = diag_stamp[16];
+            record[3] = diag_stamp[17];
+            record[4] = wall_clock64();
+            record[5] = static_cast<unsigned long long>(first_column);
+            record[6] = static_cast<unsigned long long>(far_columns);
+            record[7] = 1;
         }
     }
-    if (threadIdx.x == 0 && trsv_wide_diag_workgroups != nullptr) {
-        unsigned long long *record =
-            trsv_wide_diag_workgroups +
-            (block * trsv_wide_max_parts + part) * 8;
-        record[0] = diag_stamp[0];
-        record[1] = helper_part ? diag_stamp[12] : diag_stamp[1];
-        record[2] = diag_stamp[16];
-        record[3] = diag_stamp[17];
-        record[4] = wall_clock64();
-        record[5] = static_cast<unsigned long long>(first_column);
-        record[6] = static_cast<unsigned long long>(far_columns);
-        record[7] = 1;
-    }
-#endif
 
     finish();
     return Persistent;
@@ -1699,18 +1332,31 @@ __device__ __forceinline__ bool trsv_wide_ticket(MtxView mtx, XView x,
  *  invariant in that loop and was computed, and kept, in front of it: 256
  *  registers and 670-780 bytes of scratch, solves 60-80 % slower
  *  (profiles/r04_trsv_persistent.txt). Arguments of a device function travel
- *  in vector registers; what is uniform is brought back into scalar ones. */
+ *  in vector registers; what is uniform is brought back into scalar ones, and
+ *  the pointers are typed as pointers into global memory (`global_ptr`: as
+ *  plain `T *` they were flat pointers here, every matrix load a `flat_load`
+ *  that every LDS wait waited for - the first out-of-line build, 6-12 % slower
+ *  than one workgroup per ticket, profiles/r05_trsv_persistent.txt). */
 template <bool Upper, bool UnitDiag, int Vec, int PanelCols, int Depth,
-          int DeepDepth, typename ArType, typename MtxView, typename XView>
-__device__ __noinline__ bool trsv_wide_ticket_call(MtxView mtx, XView x,
-                                                   std::uint32_t *helper,
-                                                   trsv_session session,
-                                                   trsv_wide_split split)
+          int DeepDepth, typename ArType, typename MtxView, typename XView,
+          typename StType>
+__device__ __noinline__ bool trsv_wide_ticket_call(
+    index_type unknowns, index_type lda, index_type x_inc,
+    global_ptr<const StType> a_data, global_ptr<StType> x_data,
+    global_ptr<std::uint32_t> helper, global_ptr<trsv_state> state,
+    global_ptr<granule_word> granules, index_type capacity_words,
+    std::uint32_t serial, trsv_wide_split split)
 {
+    trsv_session session{};
+    session.state = (trsv_state *)wave_uniform(state);
+    session.granules = (granule_word *)wave_uniform(granules);
+    session.capacity_words = wave_uniform(capacity_words);
+    session.serial = wave_uniform(serial);
     return trsv_wide_ticket<Upper, UnitDiag, Vec, PanelCols, Depth, DeepDepth,
-                            ArType, true>(
-        wave_uniform(mtx), wave_uniform(x), wave_uniform(helper),
-        wave_uniform(session), wave_uniform(split));
+                            ArType, true, MtxView, XView>(
+        wave_uniform(unknowns), wave_uniform(lda), wave_uniform(x_inc),
+        (const StType *)wave_uniform(a_data), (StType *)wave_uniform(x_data),
+        (std::uint32_t *)wave_uniform(helper), session, wave_uniform(split));
 }
 }  // namespace detail
 
@@ -1729,16 +1375,28 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
     MtxView mtx, XView x, std::uint32_t *helper, trsv_session session,
     trsv_wide_split split)
 {
+    using st_type =
+        std::remove_cv_t<typename view_traits<XView>::storage_type>;
+    const st_type *a_data = view_traits<MtxView>::data(mtx);
+    st_type *x_data = view_traits<XView>::data(x);
+    const index_type unknowns = mtx.length(0);
+    const index_type lda = view_traits<MtxView>::stride(mtx);
+    const index_type x_inc = view_traits<XView>::stride(x);
     if constexpr (Persistent) {
         while (detail::trsv_wide_ticket_call<Upper, UnitDiag, Vec, PanelCols,
-                                             Depth, DeepDepth, ArType>(
-            mtx, x, helper, session, split)) {
+                                             Depth, DeepDepth, ArType, MtxView,
+                                             XView, st_type>(
+            unknowns, lda, x_inc, (global_ptr<const st_type>)a_data,
+            (global_ptr<st_type>)x_data, (global_ptr<std::uint32_t>)helper,
+            (global_ptr<trsv_state>)session.state,
+            (global_ptr<granule_word>)session.granules, session.capacity_words,
+            session.serial, split)) {
             __syncthreads();  // the next ticket's work re-uses what lives in LDS
         }
     } else {
         detail::trsv_wide_ticket<Upper, UnitDiag, Vec, PanelCols, Depth,
-                                 DeepDepth, ArType, false>(mtx, x, helper,
-                                                           session, split);
+                                 DeepDepth, ArType, false, MtxView, XView>(
+            unknowns, lda, x_inc, a_data, x_data, helper, session, split);
     }
 }
 
@@ -1746,294 +1404,8 @@ __global__ __launch_bounds__(trsv_wide_waves *wave_size) void trsv_wide(
 }  // namespace kernel
 
 
-/** Dynamic LDS on top of the static arrays so that ONE workgroup is resident
- *  per CU (see `trsv_single_block_pad`); fp64 arithmetic needs none (136 KiB
- *  of static LDS). */
-template <typename ArType>
-constexpr unsigned trsv_wide_single_block_pad()
-{
-    constexpr std::size_t H = trsv_tile;
-    constexpr std::size_t static_bytes =
-        sizeof(ArType) * (4 * H * (H + 1) + 3 * trsv_wide_rows) + 16;
-    constexpr std::size_t needed = 160 * 1024 / 2 + 2048;
-    return static_bytes >= needed
-               ? 0u
-               : static_cast<unsigned>(needed - static_bytes);
-}
-
-
-/** Operands the 128-row kernel takes: those whose rows the sweeps may read
- *  with 16-byte loads (`trsv_vector_rows`: any since round 4; only aligned
- *  bases and row strides with `any_alignment` = false). */
-template <typename MtxView>
-bool trsv_wide_applicable(bool upper, const MtxView &mtx,
-                          bool any_alignment = true)
-{
-    (void)upper;  // (upper solves of any n: mirrored around a virtual size)
-    return trsv_vector_rows(mtx, any_alignment);
-}
-
-
-#ifndef ACCBLAS_TRSV_WIDE_PARTS
-#define ACCBLAS_TRSV_WIDE_PARTS 5
-#endif
-#ifndef ACCBLAS_TRSV_WIDE_TAIL_PARTS
-#define ACCBLAS_TRSV_WIDE_TAIL_PARTS 8
-#endif
-#ifndef ACCBLAS_TRSV_WIDE_TAIL_BLOCKS
-#define ACCBLAS_TRSV_WIDE_TAIL_BLOCKS 32
-#endif
-#ifndef ACCBLAS_TRSV_WIDE_MAX_TAIL_BLOCKS
-#define ACCBLAS_TRSV_WIDE_MAX_TAIL_BLOCKS 96
-#endif
-#ifndef ACCBLAS_TRSV_WIDE_LAST_PARTS
-#define ACCBLAS_TRSV_WIDE_LAST_PARTS 16
-#endif
-#ifndef ACCBLAS_TRSV_WIDE_TAIL_DEFERRED
-#define ACCBLAS_TRSV_WIDE_TAIL_DEFERRED 16
-#endif
-#ifndef ACCBLAS_TRSV_WIDE_WHOLE_BLOCKS
-#define ACCBLAS_TRSV_WIDE_WHOLE_BLOCKS 64
-#endif
-
-/** How a solve of n unknowns is split on a device with `num_cus` CUs: row
- *  blocks that cannot be resident from the start (more blocks than CUs) get
- *  ACCBLAS_TRSV_WIDE_PARTS workgroups each (4 helpers + the owner), the last
- *  ACCBLAS_TRSV_WIDE_TAIL_BLOCKS of them ACCBLAS_TRSV_WIDE_TAIL_PARTS, their
- *  owners keeping ACCBLAS_TRSV_WIDE_TAIL_DEFERRED block columns only: the
- *  workgroups with the last tickets run almost alone, so their shares decide
- *  how long the solve's tail is. Measured (profiles/r02_trsv_split_ab.txt,
- *  us, unsplit -> 5 parts -> 5 parts + 8 for the last 64 blocks):
- *  n = 40000: 845-863 -> 747-785 -> 748-778; n = 65536: 1554 -> 1563-1608 ->
- *  1496-1500; the other tail shapes tried since are within 2 % of each other
- *  (profiles/r02_trsv_split_first.txt).
- *  Round 3: the solve's drain - the time between the last ticket and the last
- *  publication, CUs going idle one by one - is as long as the last shares take
- *  at what ONE workgroup streams (39 GB/s: 4.5 MB shares, 110-130 us at
- *  n = 65536, profiles/r03_trsv_tail.txt). Large solves therefore get a longer
- *  tail (all split blocks but the first 32, up to
- *  ACCBLAS_TRSV_WIDE_MAX_TAIL_BLOCKS) whose last third has
- *  ACCBLAS_TRSV_WIDE_LAST_PARTS workgroups per block: 65536 -1.5...-3 %, 57344
- *  -1...-1.7 %, 40000-49152 unchanged within +-0.3 %; 24 or 32 parts for the
- *  last blocks are no better than 16 (every part costs its owner a wait). */
-inline trsv_wide_split trsv_wide_split_for(index_type n, int num_cus,
-                                           int split_from = 0)
-{
-    const int blocks = static_cast<int>(ceildiv(n, index_type{trsv_wide_rows}));
-    // a split block must defer its fold (2 x deferred + 1 far columns at least)
-    constexpr int min_first = 2 * static_cast<int>(trsv_wide_deferred_columns) + 2;
-    // The first blocks beyond the CU count stay whole: the owner of a split
-    // block starts when the front is still far away (a CU frees up per hop AND
-    // per finished helper) and then holds its CU idle, a whole block that
-    // starts early sweeps its own columns meanwhile. Up to 64 of them, half of
-    // what there is (profiles/r02_trsv_split_first.txt: first split block
-    // 256 -> 320 at n = 49152 / 57344 / 65536: 965 -> 922, 1190 -> 1128,
-    // 1447 -> 1414 us; n = 40000, 313 blocks: 288 as good as 256, none worse)
-    int whole = blocks > num_cus ? (blocks - num_cus) / 2 : 0;
-    whole = whole < ACCBLAS_TRSV_WIDE_WHOLE_BLOCKS ? whole
-                                                   : ACCBLAS_TRSV_WIDE_WHOLE_BLOCKS;
-    // (`split_from` > 0: the caller's choice of the first split block)
-    const int wanted = split_from > 0 ? split_from : num_cus + whole;
-    const int first = wanted > min_first ? wanted : min_first;
-    if (ACCBLAS_TRSV_WIDE_PARTS > 1 && blocks > first) {
-        const int split_blocks = blocks - first;
-        int tail_blocks = split_blocks - ACCBLAS_TRSV_WIDE_TAIL_BLOCKS;
-        tail_blocks = tail_blocks > ACCBLAS_TRSV_WIDE_MAX_TAIL_BLOCKS
-                          ? ACCBLAS_TRSV_WIDE_MAX_TAIL_BLOCKS
-                          : tail_blocks;
-        tail_blocks = tail_blocks < ACCBLAS_TRSV_WIDE_TAIL_BLOCKS
-                          ? ACCBLAS_TRSV_WIDE_TAIL_BLOCKS
-                          : tail_blocks;
-        tail_blocks = tail_blocks < split_blocks ? tail_blocks : split_blocks;
-        const int last_blocks =
-            ACCBLAS_TRSV_WIDE_LAST_PARTS > ACCBLAS_TRSV_WIDE_TAIL_PARTS
-                ? tail_blocks / 3
-                : 0;
-        return trsv_wide_split{first,
-                               ACCBLAS_TRSV_WIDE_PARTS,
-                               blocks - tail_blocks,
-                               ACCBLAS_TRSV_WIDE_TAIL_PARTS,
-                               ACCBLAS_TRSV_WIDE_TAIL_DEFERRED,
-                               blocks - last_blocks,
-                               last_blocks > 0 ? ACCBLAS_TRSV_WIDE_LAST_PARTS : 1,
-                               0,
-                               0,
-                               0};
-    }
-    return trsv_wide_split{blocks, 1, blocks, 1,
-                           static_cast<int>(trsv_wide_deferred_columns), blocks,
-                           1, 0, 0, 0};
-}
-
-/** Tickets (units of work: row blocks, helpers' shares, prefetchers) of a
- *  solve under `split`. */
-inline unsigned trsv_wide_tickets(index_type n, const trsv_wide_split &split)
-{
-    const index_type blocks = ceildiv(n, index_type{trsv_wide_rows});
-    return static_cast<unsigned>(
-        split.first_block + (split.tail_block - split.first_block) * split.parts +
-        (split.last_block - split.tail_block) * split.tail_parts +
-        (blocks - split.last_block) * split.last_parts + split.prefetchers);
-}
-
-/** The 128-row kernel under an explicit `split` (tools; the library goes
- *  through `launch_trsv_wide`). */
-template <typename ArType, typename MtxView, typename XView>
-hipError_t launch_trsv_wide_split(bool upper, bool unit_diag,
-                                  const MtxView &mtx, const XView &x,
-                                  std::uint32_t *helper,
-                                  const trsv_session &session,
-                                  hipStream_t stream,
-                                  const trsv_wide_split &split_in,
-                                  int num_cus = 0, bool persistent_wanted = false)
-{
-    trsv_wide_split split = split_in;
-    using st_type =
-        std::remove_cv_t<typename view_traits<XView>::storage_type>;
-    static_assert(view_traits<MtxView>::is_pointer_view &&
-                      view_traits<XView>::is_pointer_view,
-                  "reduced_row_major / row_major / plain views only");
-    static_assert(ACCBLAS_TRSV_WIDE_PARTS <= trsv_wide_max_parts &&
-                      ACCBLAS_TRSV_WIDE_TAIL_PARTS <= trsv_wide_max_parts &&
-                      ACCBLAS_TRSV_WIDE_LAST_PARTS <= trsv_wide_max_parts,
-                  "too many parts");
-    if (mtx.length(0) <= 0) {
-        return hipSuccess;
-    }
-    // (the size the row blocks are laid out for, `trsv_wide_virtual_pad`)
-    const index_type n =
-        mtx.length(0) + trsv_wide_virtual_pad<st_type>(upper, mtx.length(0));
-    if (split.parts > trsv_wide_max_parts ||
-        split.tail_parts > trsv_wide_max_parts || split.parts < 1 ||
-        split.tail_parts < 1 || split.last_parts > trsv_wide_max_parts ||
-        split.last_parts < 1 || split.prefetchers < 0 ||
-        split.last_block > ceildiv(n, index_type{trsv_wide_rows}) ||
-        split.last_block < split.tail_block) {
-        return hipErrorInvalidValue;
-    }
-    if (split.parts == 1 && (split.tail_parts != 1 || split.last_parts != 1)) {
-        // (no splitting means none at all: the grid would hold workgroups
-        // that no row block is waiting for)
-        return hipErrorInvalidValue;
-    }
-    if (split.parts > 1) {
-        // a split block adds its helpers' sums where it folds its panel, which
-        // it only does late (`defer_fold`) when it has at least
-        // 2 x deferred + 1 far columns; and its owner keeps `deferred` columns,
-        // which it must have
-        constexpr int min_first =
-            2 * static_cast<int>(trsv_wide_deferred_columns) + 2;
-        if (split.first_block < min_first ||
-            split.tail_block < split.first_block || split.tail_deferred < 0 ||
-            split.tail_deferred > split.tail_block - 1) {
-            return hipErrorInvalidValue;
-        }
-    }
-    constexpr int vec16 = 16 / sizeof(st_type);
-    // a sweep step of 8-byte storage covers 64 columns: 16 load instructions
-    // per lane and step would not leave registers for two steps in flight
-    constexpr int panel_cols = sizeof(st_type) == 8 ? 64 : 128;
-    // Steps of matrix data in flight per wave. While the folded panel W (64
-    // registers with fp64 arithmetic) is live, a workgroup is at the chain's
-    // front or within 48 columns of its own diagonal - it gets one column per
-    // hop, two steps are plenty - and that is also what the 256 registers of
-    // a lane hold next to W. The bulk of a long sweep runs before W exists
-    // (`defer_fold`, helpers of split blocks): as deep as the registers allow.
-    constexpr int depth = sizeof(st_type) == 2 ? 3 : 2;
-    constexpr int deep_depth = sizeof(st_type) == 2 ? 5 : 4;
-    const unsigned tickets = trsv_wide_tickets(n, split);
-    split.tickets = static_cast<int>(tickets);
-    // (a CU for every row block: all of them start with the solve)
-    // (row blocks below the CU count start with the solve; ALWAYS_DEFER = 1:
-    // round 3's rule, every long sweep defers)
-#ifndef ACCBLAS_TRSV_WIDE_ALWAYS_DEFER
-#define ACCBLAS_TRSV_WIDE_ALWAYS_DEFER 0
-#endif
-    split.defer_from =
-        (ACCBLAS_TRSV_WIDE_ALWAYS_DEFER == 0 && num_cus > 0) ? num_cus : 0;
-    // (one workgroup per CU drawing tickets when there are more tickets than
-    // CUs; a launch with a workgroup for every ticket runs the loop-free kernel)
-    const bool persistent = persistent_wanted && num_cus > 0 &&
-                            tickets > static_cast<unsigned>(num_cus);
-    const dim3 grid(persistent ? static_cast<unsigned>(num_cus) : tickets);
-    const dim3 block(trsv_wide_waves * wave_size);
-    const unsigned pad = trsv_wide_single_block_pad<ArType>();
-#define ACCBLAS_TRSV_WIDE_LAUNCH(_upper, _unit)                                \
-    if (persistent) {                                                          \
-        kernel::trsv_wide<_upper, _unit, vec16, panel_cols, depth, deep_depth, \
-                          ArType, true>                                        \
-            <<<grid, block, pad, stream>>>(mtx, x, helper, session, split);    \
-    } else {                                                                   \
-        kernel::trsv_wide<_upper, _unit, vec16, panel_cols, depth, deep_depth, \
-                          ArType, false>                                       \
-            <<<grid, block, pad, stream>>>(mtx, x, helper, session, split);    \
-    }
-    if (upper) {
-        if (unit_diag) {
-            ACCBLAS_TRSV_WIDE_LAUNCH(true, true);
-        } else {
-            ACCBLAS_TRSV_WIDE_LAUNCH(true, false);
-        }
-    } else {
-        if (unit_diag) {
-            ACCBLAS_TRSV_WIDE_LAUNCH(false, true);
-        } else {
-            ACCBLAS_TRSV_WIDE_LAUNCH(false, false);
-        }
-    }
-#undef ACCBLAS_TRSV_WIDE_LAUNCH
-    return hipGetLastError();
-}
-
-/** Prefetching workgroups a solve gets (`trsv_wide_split::prefetchers`): the
- *  CUs the row blocks leave idle, up to 128 of them, where it was measured to
- *  pay. Round 3 (profiles/r03_trsv_prefetch.txt): 4-byte storage -3...-6 % and
- *  8-byte storage -12...-26 % at 32 to 144 row blocks, 2-byte storage +5 %.
- *  Round 5, re-measured under round 4's front loop (the followers' tile
- *  requests now stay in flight across a hop, so a tile that waits in the
- *  Infinity Cache buys nothing and its second trip through the fabric costs):
- *  4-byte storage is 2-5 % SLOWER with prefetchers at n = 4096 ... 12288 and
- *  8-25 % slower at 14336 ... 28000, both triangles, fp64 and fp32 arithmetic
- *  (profiles/r05_trsv_prefetch_ab.txt) - the library's sweep had a 15 % cliff at
- *  144 row blocks where the old rule switched them off. The rule is now 8-byte
- *  storage only (which the library sends to the 64-row kernel unless option
- *  "trsv_wide" = 2 asks for this one). `mode`: 0 never, 1 by that rule,
- *  2 whenever CUs are idle (measurements). */
-template <typename StType>
-inline int trsv_wide_prefetchers_for(index_type n, int num_cus, int mode)
-{
-    const int blocks = static_cast<int>(ceildiv(n, index_type{trsv_wide_rows}));
-    const int spare = num_cus - blocks;
-    if (mode == 0 || spare <= 0) {
-        return 0;
-    }
-    if (mode == 1 && (sizeof(StType) < 8 || blocks < 32 || blocks > 144)) {
-        return 0;
-    }
-    return spare < 128 ? spare : 128;
-}
-
-template <typename ArType, typename MtxView, typename XView>
-hipError_t launch_trsv_wide(bool upper, bool unit_diag, const MtxView &mtx,
-                            const XView &x, std::uint32_t *helper,
-                            const trsv_session &session, hipStream_t stream,
-                            int num_cus, int split_from = 0,
-                            int prefetch_mode = 1, int persistent_mode = 0)
-{
-    using st_type =
-        std::remove_cv_t<typename view_traits<XView>::storage_type>;
-    const index_type laid_out =
-        mtx.length(0) + trsv_wide_virtual_pad<st_type>(upper, mtx.length(0));
-    trsv_wide_split split = trsv_wide_split_for(laid_out, num_cus, split_from);
-    split.prefetchers =
-        split.parts == 1 ? trsv_wide_prefetchers_for<st_type>(
-                               laid_out, num_cus, prefetch_mode)
-                         : 0;
-    return launch_trsv_wide_split<ArType>(upper, unit_diag, mtx, x, helper,
-                                          session, stream, split, num_cus,
-                                          persistent_mode != 0);
-}
-
-
 }  // namespace dev
 }  // namespace accblas
+
+
+#include "trsv_wide_launch.hpp"

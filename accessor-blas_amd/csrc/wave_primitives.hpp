@@ -26,6 +26,17 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (wave_size - 1);
 /** Wave index inside a 1-D workgroup. */
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+/** A pointer into global memory, typed as one. Pointer parameters of a KERNEL
+ *  are known to point there; a `T *` that reaches an out-of-line device
+ *  function as an argument is a flat pointer and its loads are `flat_load`s,
+ *  which count in vmcnt AND lgkmcnt: every wait for an LDS read then waits for
+ *  every matrix load in flight. (A cast to this type and back inside the
+ *  function is folded away before the compiler's address-space inference sees
+ *  it, and `__builtin_assume(!is_shared && !is_private)` is not picked up: the
+ *  PARAMETER has to have this type.) */
+template <typename T>
+using global_ptr = T __attribute__((address_space(1))) *;
+
 /** `value` (the same in every lane) as scalar registers: lane 0's copy, word
  *  by word. Arguments of an out-of-line device function arrive in vector
  *  registers whatever they hold; what is computed from them would stay there. */

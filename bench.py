@@ -277,14 +277,15 @@ class HostStagedCollectives:
         self._dist.destroy_process_group()
 
 
-def event_times_us(accblas, torch, fn, stream, reps=5, setup=None):
+def event_times_us(accblas, torch, fn, stream, reps=5, setup=None, warmups=1):
     """(min, mean) HIP-event time of fn() in microseconds over `reps` runs after
-    one warm-up. `setup()` (e.g. restoring an in-place operand) is enqueued
-    BEFORE the start event, so the bracket holds fn()'s launches and nothing
-    else - nothing is subtracted afterwards."""
-    if setup is not None:
-        setup()
-    fn()
+    `warmups` untimed ones. `setup()` (e.g. restoring an in-place operand) is
+    enqueued BEFORE the start event, so the bracket holds fn()'s launches and
+    nothing else - nothing is subtracted afterwards."""
+    for _ in range(warmups):
+        if setup is not None:
+            setup()
+        fn()
     torch.cuda.synchronize()
     times = []
     for _ in range(reps):
@@ -325,7 +326,36 @@ def recomputable(kernel, algorithmic_bytes, us_min, us_mean, protocol):
     return {"kernel": kernel, "algorithmic_bytes": algorithmic_bytes,
             "us_min": us_min, "us_mean": us_mean, "protocol": protocol,
             "GBs": algorithmic_bytes / us_min / 1e3,
-            "frac_of_8TBs": algorithmic_bytes / us_min / 1e3 / HBM_PEAK_GBS}
+            "frac_of_8TBs": algorithmic_bytes / us_min / 1e3 / HBM_PEAK_GBS,
+            "frac_of_8TBs_mean": algorithmic_bytes / us_mean / 1e3 / HBM_PEAK_GBS}
+
+
+def recorded_traffic(entry):
+    """`traffic_over_algorithmic` of one kernel, replayed from profiles/traffic.json
+    (the builder's rocprofv3 --pmc passes: 2 * FETCH_SIZE + WRITE_SIZE, separate
+    runs) if the kernel's sources still hash to what the counters were taken on;
+    otherwise the reason there is none. Never measured in this run."""
+    import hashlib
+    path = os.path.join(REPO, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return {"traffic_over_algorithmic": None, "traffic_source": "none: no profiles/traffic.json"}
+    with open(path) as f:
+        recorded = json.load(f).get("kernels", {}).get(entry)
+    if recorded is None:
+        return {"traffic_over_algorithmic": None,
+                "traffic_source": f"none: no counters recorded for {entry}"}
+    digest = hashlib.sha256()
+    for name in recorded["sources"]:
+        with open(os.path.join(REPO, "accessor-blas_amd", "csrc", name), "rb") as f:
+            digest.update(f.read())
+    if digest.hexdigest() != recorded["sources_sha256"]:
+        return {"traffic_over_algorithmic": None,
+                "traffic_source": f"none: kernel changed ({', '.join(recorded['sources'])}) since "
+                                  f"the counters in {recorded['source']} were taken"}
+    return {"traffic_over_algorithmic": recorded["traffic_over_algorithmic"],
+            "traffic_bytes_per_launch": recorded.get("bytes_per_launch"),
+            "traffic_source": f"replayed from {recorded['source']} (rocprofv3 --pmc passes on this "
+                              "version of the kernel; not measured in this run)"}
 
 
 def other_configs(accblas, torch, dev, stream, dist, world, rank, headline=None):
@@ -366,7 +396,8 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank, headline=None)
         plain_us=t_plain, plain_us_mean=t_plain_mean, acc_us=t_acc,
         plain_GBs=byts / t_plain / 1e3, acc_GBs=byts / t_acc / 1e3,
         acc_frac_of_8TBs=byts / t_acc / 1e3 / HBM_PEAK_GBS,
-        plain_equals_accessor_bitwise=identical)
+        plain_equals_accessor_bitwise=identical,
+        **recorded_traffic("gemv_16384_fp64_fp64"))
     del A, x, r0, r_plain, r_acc
 
     # -- the shape ONE GPU of an 8-GPU run of the headline problem sees: a row
@@ -401,7 +432,8 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank, headline=None)
             rows=share, cols=hcols,
             us_back_to_back=t_b2b, us_back_to_back_mean_of_10_batches=t_b2b_mean,
             frac_of_8TBs_back_to_back=byts / t_b2b / 1e3 / HBM_PEAK_GBS,
-            us_same_row_block=t_same)
+            us_same_row_block=t_same,
+            **recorded_traffic("gemv_rowblock_4096x32768"))
 
     # -- configs[3]: dot n = 2^28, storage fp16, arithmetic fp32, chunked over the
     # ranks, one all-reduce of a single fp32 element
@@ -463,6 +495,9 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank, headline=None)
     out["dot_2p28_fp16_fp32"] = {
         "kernel": "accblas::dev::kernel::dot (Acc<fp32, fp16>, deterministic hand-off)",
         "algorithmic_bytes": 4.0 * count, "us_min": t_kernel, "us_mean": t_kernel_mean,
+        "frac_of_8TBs": 4.0 * count / t_kernel / 1e3 / HBM_PEAK_GBS,
+        "frac_of_8TBs_mean": 4.0 * count / t_kernel_mean / 1e3 / HBM_PEAK_GBS,
+        **recorded_traffic("dot_2p28_fp16_fp32"),
         "protocol": f"min / mean over 10 batches of {reps} back-to-back launches sweeping "
                     f"{copies} buffer sets in turn (per-launch average)",
         "elements_per_gpu": count, "kernel_us": t_kernel,
@@ -508,6 +543,9 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank, headline=None)
         out["dot_chunk_2p25_fp16_fp32_one_gpu_share_of_8"] = {
             "kernel": "accblas::dev::kernel::dot (Acc<fp32, fp16>, deterministic hand-off)",
             "algorithmic_bytes": 4.0 * chunk, "us_min": t_hbm, "us_mean": t_hbm_mean,
+            "frac_of_8TBs": 4.0 * chunk / t_hbm / 1e3 / HBM_PEAK_GBS,
+            "frac_of_8TBs_mean": 4.0 * chunk / t_hbm_mean / 1e3 / HBM_PEAK_GBS,
+            **recorded_traffic("dot_chunk_2p25_fp16_fp32"),
             "elements": chunk, "bytes": 4 * chunk,
             "hbm_us_back_to_back": t_hbm,
             "hbm_GBs": 4.0 * chunk / t_hbm / 1e3,
@@ -542,8 +580,10 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank, headline=None)
             # the reference's protocol (warm-up, then the minimum of 10 runs,
             # cuda/utils.cuh:236-262) with x restored BEFORE the start event:
             # the bracket holds the solve's one launch and nothing else
-            t_trsv, t_trsv_mean = event_times_us(accblas, torch, solve, stream, reps=10,
-                                                 setup=lambda: xs.copy_(b))
+            # (five warm-ups: the first solves after another workload run 3-8 %
+            # slower - profiles/r05_trsv_spread_before.txt, "seq" -, twenty timed)
+            t_trsv, t_trsv_mean = event_times_us(accblas, torch, solve, stream, reps=20,
+                                                 setup=lambda: xs.copy_(b), warmups=5)
             xs.copy_(b)
             solve()
             torch.cuda.synchronize()
@@ -559,8 +599,9 @@ def other_configs(accblas, torch, dev, stream, dist, world, rank, headline=None)
             out[f"trsv_{n}_{uplo_name}_unit_fp32_{'fp64' if ar == F64 else 'plain_fp32'}"] = dict(
                 recomputable("accblas::dev::kernel::trsv_wide", byts, t_trsv, t_trsv_mean,
                              "x restored by a device copy enqueued before the start event; "
-                             "warm-up, then min / mean of 10 event-timed solves (one launch "
+                             "5 warm-ups, then min / mean of 20 event-timed solves (one launch "
                              "each)"),
+                **recorded_traffic(f"trsv_{n}_{uplo_name}_{'fp64' if ar == F64 else 'fp32'}_fp32"),
                 us=t_trsv, us_per_128row_hop=t_trsv / (n / 128),
                 sampled_residual_rel=float(resid.abs().sum() / b.double()[rows].abs().sum()),
                 helper_word=int(helper[0].item()) & 0xffffffff)
@@ -823,25 +864,10 @@ def main():
     }
     if multi is not None:
         out["multi_gpu"] = multi
-    traffic_file = os.path.join(REPO, "profiles", "traffic.json")
-    if os.path.exists(traffic_file) and n == 32768 and args.st == "f32" and world == 1:
-        import hashlib
-        with open(traffic_file) as f:
-            recorded = json.load(f)
-        with open(os.path.join(REPO, "accessor-blas_amd", "csrc", "gemv_kernels.hpp"),
-                  "rb") as f:
-            kernel_hash = hashlib.sha256(f.read()).hexdigest()
-        if recorded.get("gemv_kernels_sha256") == kernel_hash:
-            out["roofline"]["traffic"] = recorded.get("gemv_vec_bytes_per_launch")
-            out["roofline"]["traffic_source"] = (
-                f"replayed from {recorded.get('source')} (builder's rocprofv3 passes on "
-                "this version of the kernel: 2 * FETCH_SIZE + WRITE_SIZE, separate --pmc "
-                "runs); not measured in this run")
-        else:
-            # counters of another version of the kernel say nothing about this one
-            out["roofline"]["traffic_source"] = (
-                "none: csrc/gemv_kernels.hpp changed since the counters in "
-                f"{recorded.get('source')} were taken (re-run tools/gpu_profile.sh)")
+    if n == 32768 and args.st == "f32" and world == 1:
+        replay = recorded_traffic("gemv_32768_fp64_fp32")
+        out["roofline"]["traffic"] = replay.get("traffic_bytes_per_launch")
+        out["roofline"]["traffic_source"] = replay["traffic_source"]
 
     # ---- accuracy on rank 0: the reference's metric sum|ref - res| / sum|ref|
     # (gemv_benchmark.cu:101-124) against the fp64 kernel on the unrounded data

@@ -45,6 +45,12 @@ def pytest_sessionstart(session):
                        stdout=subprocess.DEVNULL)
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """The TRSV parity errors this session measured (tests/trsv_margins.py)."""
+    import trsv_margins
+    trsv_margins.dump()
+
+
 def _gpu_available():
     try:
         import torch

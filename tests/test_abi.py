@@ -87,7 +87,7 @@ def test_options_are_validated():
     assert lib.accblas_set_option(b"trsv_wide_split_from", 0) == 0
     for name, default in ((b"gemv_skew", 1), (b"trsv_relay", 1), (b"trsv_wide", 1),
                           (b"trsv_prefetch", 1), (b"trsv_small", 1), (b"trsv_vector_rows", 1),
-                          (b"gemv_vector_rows", 1)):
+                          (b"gemv_vector_rows", 1), (b"trsv_wide_persistent", 0)):
         assert lib.accblas_set_option(name, 3) == -2
         assert lib.accblas_set_option(name, default) == 0
 

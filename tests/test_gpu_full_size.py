@@ -198,21 +198,33 @@ def test_config_c5_trsv_65536_fp32_storage_fp64_arithmetic(gpu, upper):
 
 
 def test_trsv_24000_matches_reference_shape_both_paths(gpu):
-    """The reference's default size (n = 24000, lda = 24000): vector path (lower,
-    aligned) and scalar fallback (misaligned base) give the same solution to
-    rounding."""
+    """The reference's default size (n = 24000, lda = 24000), a matrix whose base
+    is misaligned by 4 bytes: the 16-byte-load path every operand takes since
+    round 4 and the element-wise 64-row kernel such operands took until then
+    (option "trsv_vector_rows" = 0) give the same solution to rounding, and the
+    misaligned operand gives the BITS of the aligned one on the vector path
+    (alignment changes addresses, not the order of summation)."""
     torch, accblas = gpu
     n = 24000
     T = uniform(torch, n * n + 1, torch.float32, 12, scale=1.0 / n ** 0.5)
     b = uniform(torch, n, torch.float32, 13)
     helper = torch.zeros(2, dtype=torch.int32, device="cuda")
-    x_vec, x_scalar = b.clone(), b.clone()
+    x_aligned, x_vec, x_scalar = b.clone(), b.clone(), b.clone()
     aligned = T[:n * n].clone()
-    accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, aligned, n, x_vec, 1, helper)
-    shifted = T[1:]  # base misaligned by 4 bytes -> Vec = 1 kernel
+    accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, aligned, n, x_aligned, 1, helper)
+    shifted = T[1:]  # base misaligned by 4 bytes
     shifted.copy_(aligned)
-    accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, shifted, n, x_scalar, 1, helper)
-    torch.cuda.synchronize()
+    accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, shifted, n, x_vec, 1, helper)
+    accblas.set_option("trsv_vector_rows", 0)  # -> the Vec = 1 instantiation, 64-row blocks
+    try:
+        accblas.acc_trsv(F64, F32, accblas.LOWER, accblas.UNIT, n, shifted, n, x_scalar, 1,
+                         helper)
+        torch.cuda.synchronize()
+    finally:
+        accblas.set_option("trsv_vector_rows", 1)
+    assert int(helper[0].item()) & 0xffffffff == 0xffffffff
+    assert torch.equal(x_aligned, x_vec)
+    assert not torch.equal(x_vec, x_scalar)  # (two kernels: 128- and 64-row blocks)
     assert rel_l1(torch, x_vec, x_scalar) <= 1e-6
 
 

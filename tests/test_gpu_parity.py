@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as oracle
+import trsv_margins
 from oracle_lib import F16, F32, F64
 
 pytestmark = pytest.mark.gpu
@@ -428,11 +429,14 @@ def test_acc_trsv_matches_oracle(gpu, trsv_kernel, ar, st, upper, unit, n, lda):
     got = dx.cpu().numpy()
     err = oracle.rel_error(want.astype(np.float64), got.astype(np.float64))
     # a triangular solve amplifies rounding by the factor's condition number;
-    # the LU-derived factors used here keep that within ~1e2
-    assert err <= 100 * out_tolerance(ar, st), (err, n)
+    # the LU-derived factors used here keep that within ~1e2: 100 x D4 is the
+    # blanket bound, 4 x the measured maximum of this (family, Ar, St, uplo)
+    # the one that is asserted (tests/trsv_margins.py)
+    blanket = 100 * out_tolerance(ar, st)
+    trsv_margins.check(trsv_margins.key(trsv_kernel, ar, st, upper, "exact_trsv"), err, blanket)
     emulated = oracle.ref_trsv(ar, upper, unit, n, A, lda, b, 1)
     err2 = oracle.rel_error(emulated.astype(np.float64), got.astype(np.float64))
-    assert err2 <= 100 * out_tolerance(ar, st), (err2, n)
+    trsv_margins.check(trsv_margins.key(trsv_kernel, ar, st, upper, "ref_trsv"), err2, blanket)
 
 
 @pytest.mark.parametrize("trsv_kernel", ["rows64", "rows128"], indirect=True)
@@ -489,8 +493,9 @@ def test_small_systems_by_one_workgroup(gpu, vt, upper, unit, n):
     assert torch.equal(x_plain, x_acc)
     got = x_plain.cpu().numpy()
     tol = 100 * out_tolerance(vt, vt)
-    assert oracle.rel_error(want[::incx][:n].astype(np.float64),
-                            got[offset::incx][:n].astype(np.float64)) <= tol
+    trsv_margins.check(trsv_margins.key("one_workgroup", vt, vt, upper, "exact_trsv"),
+                       oracle.rel_error(want[::incx][:n].astype(np.float64),
+                                        got[offset::incx][:n].astype(np.float64)), tol)
     assert oracle.rel_error(x_blocked.cpu().numpy()[offset::incx][:n].astype(np.float64),
                             got[offset::incx][:n].astype(np.float64)) <= tol
     untouched = np.ones(got.size, dtype=bool)

@@ -28,6 +28,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as oracle
+import trsv_margins
 from oracle_lib import F32, F64
 from test_gpu_parity import out_tolerance
 
@@ -184,7 +185,8 @@ def test_trsv_variants_on_the_reference_inputs(gpu, trsv_inputs, n):
         exact = oracle.exact_trsv(ar, True, True, n, A, lda, x[:n], 1)
         for label, want in (("ref_trsv", emulated), ("exact_trsv", exact)):
             err = oracle.rel_error(want.astype(np.float64), got.astype(np.float64))
-            assert err <= tol, (name, n, label, err)
+            trsv_margins.check(trsv_margins.key("reference_inputs_" + ("plain" if plain else "acc"),
+                                                ar, st, True, label), err, tol)
     assert np.array_equal(results["fp64"], results["Acc<fp64, fp64>"])
     assert np.array_equal(results["fp32"], results["Acc<fp32, fp32>"])
     ref64 = results["fp64"]

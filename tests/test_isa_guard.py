@@ -32,6 +32,14 @@ hipError_t wide32(const c_range32 &m, const range32 &x, std::uint32_t *helper, c
 {
     return launch_trsv_wide<float>(true, true, m, x, helper, s, nullptr, 256);
 }
+// 2-byte storage (general sweep, ring of three tiles)
+using acc16 = gko::acc::reduced_row_major<2, double, _Float16>;
+using range16 = gko::acc::range<acc16>;
+using c_range16 = gko::acc::range<acc16::const_accessor>;
+hipError_t wide16(const c_range16 &m, const range16 &x, std::uint32_t *helper, const trsv_session &s)
+{
+    return launch_trsv_wide<double>(false, true, m, x, helper, s, nullptr, 256);
+}
 hipError_t narrow(const c_range &m, const range &x, std::uint32_t *helper, const trsv_session &s)
 {
     return launch_trsv<double>(false, true, m, x, helper, s, nullptr, 0);
@@ -69,8 +77,11 @@ def refills_without_a_full_wait(body):
 def kernels(asm):
     """name -> body of every kernel in the assembly listing."""
     out = {}
-    for match in re.finditer(r"^(_Z\w+):.*?\n(.*?)s_endpgm", asm, flags=re.S | re.M):
-        out[match.group(1)] = match.group(2)
+    # (kernels only: device functions that are not inlined have labels of the
+    # same form and end in s_setpc_b64)
+    for name in re.findall(r"^\s*\.amdhsa_kernel (\S+)", asm, flags=re.M):
+        match = re.search(r"^" + re.escape(name) + r":.*?\n(.*?)s_endpgm", asm, flags=re.S | re.M)
+        out[name] = match.group(1)
     return out
 
 
@@ -99,10 +110,16 @@ def test_trsv_tile_staging_is_one_batch_of_loads_and_nothing_spills(tmp_path):
                    check=True, capture_output=True, timeout=600)
     asm = asm_path.read_text()
     found = kernels(asm)
-    wide = {k: v for k, v in found.items() if "9trsv_wide" in k}
+    # the loop-free form (what the library launches by default) and the ticket
+    # loop's form (option "trsv_wide_persistent") of every 128-row kernel
+    looped = {k: v for k, v in found.items() if "9trsv_wide" in k and re.search(r"E[df]Lb1EN3gko", k)}
+    wide = {k: v for k, v in found.items() if "9trsv_wide" in k and k not in looped}
     narrow = {k: v for k, v in found.items() if "kernel4trsv" in k}
-    assert len(wide) == 8 and narrow, sorted(found)  # (uplo x diag) x (fp64, fp32 arithmetic)
+    # (uplo x diag) x (fp64 / fp32 arithmetic on fp32 storage, fp64 arithmetic on fp16 storage)
+    assert len(wide) == 12 and len(looped) == 12 and narrow, sorted(found)
     for name, body in wide.items():
+        if "KDF16_" in name:
+            continue  # (2-byte storage stages with global_load_ushort / short_d16)
         # between the ticket barrier and the "tiles staged" barrier: 3 tiles x
         # 8 rows per wave plus the block's own right-hand side, one batch
         # (the staging code sits between two barriers; which ones, in the order
@@ -126,11 +143,26 @@ def test_trsv_tile_staging_is_one_batch_of_loads_and_nothing_spills(tmp_path):
     for name in deep:
         assert refills_without_a_full_wait(relay[name]) >= 3, \
             (name, refills_without_a_full_wait(relay[name]))
-    # register budget of the 128-row kernel: two waves per SIMD, no scratch
+    # register budget of the 128-row kernel, every instantiation the library
+    # dispatches to by default: two waves per SIMD (at most 256 registers; the
+    # fp64-arithmetic kernels of 4-byte storage sit at 253-255), nothing spilled,
+    # no private segment
     for name in wide:
         meta = re.search(r"\.name:\s+" + re.escape(name) + r"\n(.*?)\.wavefront_size", asm, flags=re.S)
         block = asm[asm.index(".amdhsa_kernel " + name):]
         block = block[:block.index(".end_amdhsa_kernel")]
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", block).group(1))
+        vgprs = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", block).group(1))
         assert scratch == 0, (name, scratch)
+        assert vgprs <= 256, (name, vgprs)
         assert meta is None or ".vgpr_spill_count: 0" in meta.group(1) or "vgpr_spill_count" not in meta.group(1)
+    # The ticket loop calls the row block as an out-of-line function. A pointer
+    # that reaches a device function as a plain `T *` is a flat pointer: every
+    # matrix load a flat_load, which counts in lgkmcnt as well and makes each
+    # wait for an LDS read a wait for the ring of tiles (round 5: 6-12 % slower).
+    # The parameters are typed `global_ptr<T>`: no flat access anywhere.
+    functions = re.findall(r"^(_Z\w*trsv_wide_ticket_call\w*):.*?\n(.*?)s_setpc_b64 s\[30:31\]", asm,
+                           flags=re.S | re.M)
+    assert len(functions) == 12, [name for name, _ in functions]
+    for name, body in functions:
+        assert "flat_load" not in body and "flat_store" not in body and "flat_atomic" not in body, name

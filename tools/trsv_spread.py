@@ -18,6 +18,7 @@ REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 ST = {"f16": (0, torch.float16), "f32": (1, torch.float32), "f64": (2, torch.float64)}
 AR = {"f32": 1, "f64": 2}
 UNIT = 1
+DEFAULTS = {"trsv_wide_split_from": 0, "trsv_wide_persistent": 0}  # (every other option: 1)
 
 reps = int(sys.argv[1])
 cases = sys.argv[2].split(",")
@@ -62,7 +63,7 @@ for case in cases:
           f"max {ordered[-1]:.1f} mean {mean:.1f} us; mean/min {mean / ordered[0]:.3f} "
           f"max/min {ordered[-1] / ordered[0]:.3f}", flush=True)
     print("   seq: " + " ".join(f"{t:.0f}" for t in times), flush=True)
-    for one in settings:  # back to the defaults the probe knows of
+    for one in settings:  # back to the library's defaults
         option = one.partition("=")[0]
-        lib.accblas_set_option(option.encode(), 1 if option != "trsv_wide_split_from" else 0)
+        lib.accblas_set_option(option.encode(), DEFAULTS.get(option, 1))
     del A
