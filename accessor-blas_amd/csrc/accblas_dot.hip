@@ -39,6 +39,17 @@ int validate_dot(const accblas_handle *handle, int64_t n, const void *x,
 }  // namespace
 
 
+namespace {
+/** status[1] <- status[0], status[0] <- 0, as one atomic exchange (the 16-byte
+ *  status slot of a handle's workspace: word 0 = the sticky mark the dot
+ *  kernels write, word 1 = what the last `accblas_dot_status` took). */
+__global__ void take_dot_status(std::uint32_t *status)
+{
+    status[1] = atomicExch(&status[0], 0u);
+}
+}  // namespace
+
+
 extern "C" {
 
 
@@ -117,27 +128,33 @@ int accblas_dot_status(accblas_handle *handle, void *stream, int *expired)
         return accblas::set_error(ACCBLAS_ERR_NULL_POINTER,
                                   "dot_status: handle or expired is NULL");
     }
-    int status = accblas::check_hip(
-        hipStreamSynchronize(accblas::as_stream(stream)),
-        "hipStreamSynchronize");
+    // Everything on the caller's stream (nothing on the legacy null stream,
+    // which would synchronise with every blocking stream): a one-thread kernel
+    // takes the mark with an atomic exchange - read and clear in one step, so a
+    // dot of this handle that expires on another stream meanwhile is reported
+    // by the next call instead of being wiped -, the copy follows it in stream
+    // order, then the stream is synchronised.
+    hipStream_t queue = accblas::as_stream(stream);
+    std::uint32_t *status_words = handle->dot_ws.status;
+    take_dot_status<<<dim3(1), dim3(1), 0, queue>>>(status_words);
+    int status = accblas::check_hip(hipGetLastError(), "dot status launch");
     if (status != ACCBLAS_OK) {
         return status;
     }
     std::uint32_t word = 0;
     status = accblas::check_hip(
-        hipMemcpy(&word, handle->dot_ws.status, sizeof(word),
-                  hipMemcpyDeviceToHost),
-        "hipMemcpy(dot status)");
+        hipMemcpyAsync(&word, status_words + 1, sizeof(word),
+                       hipMemcpyDeviceToHost, queue),
+        "hipMemcpyAsync(dot status)");
+    if (status != ACCBLAS_OK) {
+        return status;
+    }
+    status = accblas::check_hip(hipStreamSynchronize(queue),
+                                "hipStreamSynchronize");
     if (status != ACCBLAS_OK) {
         return status;
     }
     *expired = word == accblas::dev::dot_expired_word ? 1 : 0;
-    if (*expired != 0) {
-        // reported once
-        status = accblas::check_hip(
-            hipMemset(handle->dot_ws.status, 0, sizeof(word)),
-            "hipMemset(dot status)");
-    }
     return status;
 }
 

@@ -82,8 +82,14 @@ int trsv_vector_rows_option_value();
 int trsv_small_option_value();
 
 /** Where the 128-row kernel is the faster one. 2- and 4-byte storage: from
- *  n = 4096 on (profiles/r02_trsv_ab_final.txt: 4-7 % faster at 4096, 17-20 % at
- *  8192, 27-50 % at 24000-65536). 8-byte storage: nowhere any more. Until round
+ *  n = 3328 (26 row blocks) on. Rounds 2-4 switched at 4096
+ *  (profiles/r02_trsv_ab_final.txt: 4-7 % faster there, 17-20 % at 8192, 27-50 %
+ *  at 24000-65536), which left the reference's sweep 3-7 % slower at n = 3800 ...
+ *  4000 than at 4100; measured in round 5 with the two kernels alternated solve
+ *  by solve inside a 24000-wide matrix (profiles/r05_trsv_kernel_switch.txt):
+ *  equal at 3200, the 128-row kernel 1-4 % faster at 3400 ... 3600 and 3-7 % at
+ *  3800 ... 4000 (fp64 and fp32 arithmetic; 2-byte storage from 3000 on). 8-byte
+ *  storage: nowhere any more. Until round
  *  3 the 128-row kernel (two half-width steps in flight are all its registers
  *  allow) won below 17000 and beyond 32768; since round 4 the 64-row kernel's
  *  relay variant keeps its ring of panels in flight and its workgroups draw
@@ -94,7 +100,7 @@ int trsv_small_option_value();
  *  1139 | 1270, 49152 1684 | 1726, 57344 2074 | 2082, 61440 2359 | 2333, 65536
  *  2785 | 2705 (within 3 % of each other from 52000 on). */
 #ifndef ACCBLAS_TRSV_WIDE_MIN_N
-#define ACCBLAS_TRSV_WIDE_MIN_N 4096
+#define ACCBLAS_TRSV_WIDE_MIN_N 3328
 #endif
 
 

@@ -221,7 +221,8 @@ __global__ __launch_bounds__(Config::waves *wave_size) void dot(
         const st_type *x_ptr = x_traits::data(x);
         const st_type *y_ptr = y_traits::data(y);
         const index_type all_chunks = n / Vec;
-        // slices start on 4 KiB boundaries (256 chunks of 16 bytes)
+        // slices start a multiple of 4 KiB (256 chunks of 16 bytes) behind the
+        // operands' bases - on 4 KiB boundaries when the bases are
         const index_type per_block =
             ceildiv(ceildiv(all_chunks, gridDim.x), 256) * 256;
         const index_type first =

@@ -240,8 +240,18 @@ namespace detail {
 // wrong result that the caller can detect (helper[0] != ~0u) instead of a hung
 // GPU.
 constexpr unsigned int trsv_spin_limit = 1u << 21;
-// bound of a wait that polls LDS only (one look per ~100 cycles: seconds)
-constexpr unsigned int trsv_lds_spin_limit = 1u << 25;
+// Last-resort bound of a wait that polls LDS only (the relay variant's workers
+// waiting for the loader wave). The loader is the one party that declares a
+// solve failed - its waits on memory are bounded by `trsv_spin_limit`, and it
+// raises `relay_abort` when it gives up, which is what the workers leave their
+// wait on. Their own bound only guards against a loader that never says
+// anything, and must not expire before the loader's can: the loader's worst case
+// is `trsv_spin_limit` polls of <= ~2 us each (a round trip under load plus its
+// s_sleep) = ~4 s over a whole solve; a worker looks at LDS once per ~150 cycles
+// (s_sleep(1) + the read), 2^30 looks = ~67 s, counted afresh for every panel.
+// A solve stretched by other streams' kernels therefore completes, as it does
+// in the prefetching workgroups (`prefetch_ahead`).
+constexpr unsigned int trsv_lds_spin_limit = 1u << 30;
 constexpr std::uint32_t trsv_error_word = 0xdeadbeefu;
 
 /** Returns true when the caller must stop waiting. */

@@ -167,8 +167,12 @@ struct packed {
 /** Streaming load of N storage elements by one instruction. `ptr` need only be
  *  aligned like an element (the queues run in the hardware's unaligned mode and
  *  the instruction is the same either way); a load that is not N*sizeof(T)
- *  aligned may lie across two cache lines and then costs two requests - GEMV
- *  and dot peel to an aligned start, the TRSV sweeps take rows as they come.
+ *  aligned may lie across two cache lines and then costs two requests. Only
+ *  GEMV's long-row shape (`RowAlign`: a pitch that is not a multiple of 128
+ *  bytes, or rows that are not 16-byte aligned, with enough columns) peels to
+ *  an aligned start; its other shapes, dot (chunks start at the operands'
+ *  bases as they are) and the TRSV sweeps take the data as it comes. Intended:
+ *  the bits of a result do not depend on the alignment of its operands' bases.
  *  NT = non-temporal hint (`global_load_dwordx4 ... nt`) for data that is
  *  read exactly once (the matrix in GEMV/TRSV, both vectors in dot). */
 template <int N, bool NT, typename T>

@@ -85,7 +85,7 @@ def launch_ranks(world, argv, command=None, timeout=None, poll=0.05, attempts=3)
     parent (a harness `timeout`, a cancelled job) do the same and exit with
     128 + signal; should the parent be killed outright, every rank gets
     SIGKILL from the kernel (PR_SET_PDEATHSIG), so no rank outlives it on a
-    GPU. The port is found by bind-and-close, so another process can take it
+    GPU. Rank 0's stderr is forwarded as it comes. The port is found by bind-and-close, so another process can take it
     before rank 0 binds it: a job whose rank 0 reports the address in use is
     started again on a new port (`attempts` times in all). The parent never
     imports torch or touches the GPU, and no process is replaced by another."""
@@ -99,7 +99,7 @@ def launch_ranks(world, argv, command=None, timeout=None, poll=0.05, attempts=3)
         status, text, errors = _launch_once(world, argv, command, deadline, timeout, poll)
         in_use = status not in (0, 124) and \
             ("address already in use" in errors.lower() or "EADDRINUSE" in errors)
-        sys.stderr.write(errors)
+        # (rank 0's stderr was forwarded as it came, see `_launch_once`)
         if not in_use or attempt + 1 == attempts:
             break
         print("bench.py: the rendezvous port was taken by another process; "
@@ -134,7 +134,19 @@ def _launch_once(world, argv, command, deadline, timeout, poll):
         port = s.getsockname()[1]
     children = []
     outputs = []
-    rank0_err = tempfile.TemporaryFile(mode="w+")
+    # rank 0's stderr: forwarded line by line as it comes (diagnostics stay
+    # live, and survive a parent that is killed outright) AND kept, because the
+    # retry on a taken port is decided from it
+    kept = []
+    reader = [None]
+
+    def forward(pipe):
+        for line in iter(pipe.readline, b""):
+            text = line.decode(errors="replace")
+            kept.append(text)
+            sys.stderr.write(text)
+            sys.stderr.flush()
+        pipe.close()
 
     def kill_all():
         for child in children:
@@ -150,11 +162,6 @@ def _launch_once(world, argv, command, deadline, timeout, poll):
         # (handlers run in the main thread between two bytecodes: the list of
         # children is whatever has been started so far)
         kill_all()
-        try:
-            rank0_err.seek(0)
-            sys.stderr.write(rank0_err.read())
-        except (OSError, ValueError):
-            pass
         print(f"bench.py: signal {signum}; the ranks were stopped", file=sys.stderr)
         sys.stderr.flush()
         os._exit(128 + signum)
@@ -177,8 +184,12 @@ def _launch_once(world, argv, command, deadline, timeout, poll):
             outputs.append(out)
             children.append(subprocess.Popen(
                 list(command) + list(argv), env=env, stdout=out,
-                stderr=rank0_err if rank == 0 else None,
+                stderr=subprocess.PIPE if rank == 0 else None,
                 start_new_session=True, preexec_fn=_die_with_parent))
+            if rank == 0:
+                reader[0] = threading.Thread(target=forward, args=(children[0].stderr,),
+                                             daemon=True)
+                reader[0].start()
         while True:
             codes = [child.poll() for child in children]
             failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
@@ -187,6 +198,14 @@ def _launch_once(world, argv, command, deadline, timeout, poll):
                 print(f"bench.py: rank {rank} of {world} exited with {code}; "
                       "stopping the other ranks", file=sys.stderr)
                 status = code if code > 0 else 128 - code
+                if rank != 0:
+                    # a rank that found a foreign listener on the port can fail
+                    # before rank 0 has said "address already in use": give rank
+                    # 0 a moment to exit by itself, so that the retry above sees
+                    # its message
+                    grace = time.monotonic() + 2.0
+                    while children[0].poll() is None and time.monotonic() < grace:
+                        time.sleep(poll)
                 break
             if all(c == 0 for c in codes):
                 break
@@ -200,18 +219,16 @@ def _launch_once(world, argv, command, deadline, timeout, poll):
         kill_all()
         for signum, handler in previous.items():
             signal.signal(signum, handler)
-    texts = []
-    for stream in (outputs[0] if outputs else None, rank0_err):
-        if stream is None:
-            texts.append("")
-            continue
-        stream.seek(0)
-        text = stream.read()
-        texts.append(text.decode(errors="replace") if isinstance(text, bytes) else text)
+    if reader[0] is not None:
+        reader[0].join(timeout=5.0)  # (the pipe ends with rank 0, killed or not)
+    text = ""
+    if outputs:
+        outputs[0].seek(0)
+        text = outputs[0].read()
+        text = text.decode(errors="replace") if isinstance(text, bytes) else text
     for out in outputs:
         out.close()
-    rank0_err.close()
-    return status, texts[0], texts[1]
+    return status, text, "".join(kept)
 
 
 def cpu_baseline(oracle, ar, A_rows, lda, x, res_rows, threads, cpu_reps=12):

@@ -84,7 +84,7 @@ size_t accblas_dtype_size(accblas_dtype t);
  * compile-time constants). The knobs take 0, 1 or 2 unless said otherwise.
  * Known names:
  *   "trsv_wide"   1 (default) = systems of 2- or 4-byte storage with
- *                 n >= 4096 use
+ *                 n >= 3328 use
  *                 128-row blocks (`kernel::trsv_wide`: half as many dependent
  *                 hops through memory, the folded panel held in registers),
  *                 everything else - 8-byte storage at every size - 64-row blocks
@@ -221,8 +221,12 @@ int accblas_acc_dot(accblas_handle *handle, accblas_dtype ar, accblas_dtype st,
  * CUs for that long, the collector writes NaN to *res instead of a partial
  * result, and this call says so: it synchronises `stream`, sets *expired to 1
  * if any dot on this handle gave up since the last call (and clears the
- * mark), else to 0. No reference counterpart (its atomics cannot stall,
- * cuda/dot_kernels.cuh:158-160); ACCBLAS_DOT_ATOMIC mode never waits. */
+ * mark), else to 0. The mark is read and cleared by one atomic exchange in a
+ * kernel on `stream`, followed by a copy and a synchronisation of that stream;
+ * nothing runs on the null stream. It synchronises, so it must not be called
+ * while `stream` is being captured into a graph. No reference counterpart (its
+ * atomics cannot stall, cuda/dot_kernels.cuh:158-160); ACCBLAS_DOT_ATOMIC mode
+ * never waits. */
 int accblas_dot_status(accblas_handle *handle, void *stream, int *expired);
 
 /* ---- TRSV: x <- T^{-1} x in place ----------------------------------------

@@ -18,6 +18,8 @@ for path in (os.path.join(REPO, "accessor-blas_amd", "python"),
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "perf: asserts a ratio of measured times (GPU tests; "
+                                       "deselect with -m 'gpu and not perf')")
 
 
 def pytest_sessionstart(session):

@@ -449,6 +449,7 @@ def test_trsv_loader_wave_variant_residuals(gpu, ar, st, n, tol, upper):
     assert rel <= tol, rel
 
 
+@pytest.mark.perf
 @pytest.mark.parametrize("vt", [F32, F64])
 def test_trsv_accessor_costs_nothing_over_plain_pointers(gpu, vt):
     """The reference's premise, timed: `acc_trsv<T, T>` takes as long as
@@ -485,18 +486,24 @@ def test_trsv_accessor_costs_nothing_over_plain_pointers(gpu, vt):
     for fn in (plain, acc):  # warm-up
         timed(fn)
     bits = {}
-    times = {"plain": [], "acc": []}
-    for _ in range(10):
-        for name, fn in (("plain", plain), ("acc", acc)):
-            times[name].append(timed(fn))
-            bits.setdefault(name, x.clone())
-            assert torch.equal(bits[name], x)
-    assert not accblas.trsv_status(helper)
-    assert torch.equal(bits["plain"], bits["acc"])
-    ratio = min(times["acc"]) / min(times["plain"])
-    assert abs(ratio - 1.0) <= 0.03, (ratio, times)
+    seen = []
+    for _ in range(3):  # (a timing assertion: up to three rounds of it)
+        times = {"plain": [], "acc": []}
+        for _ in range(10):
+            for name, fn in (("plain", plain), ("acc", acc)):
+                times[name].append(timed(fn))
+                bits.setdefault(name, x.clone())
+                assert torch.equal(bits[name], x)
+        assert not accblas.trsv_status(helper)
+        assert torch.equal(bits["plain"], bits["acc"])
+        ratio = min(times["acc"]) / min(times["plain"])
+        seen.append(ratio)
+        if abs(ratio - 1.0) <= 0.03:
+            return
+    raise AssertionError(seen)
 
 
+@pytest.mark.perf
 def test_an_odd_row_stride_costs_gemv_nothing_and_trsv_little(gpu):
     """What round 4 bought for operands that are not 16-byte aligned, timed on the CLIs'
     own scale: the SAME product / solve on a view with lda = n + 1 starting one element
@@ -535,11 +542,60 @@ def test_an_odd_row_stride_costs_gemv_nothing_and_trsv_little(gpu):
         return a.elapsed_ms(b) * 1e3
 
     for fn, restore, allowed in ((gemv, False, 1.08), (trsv, True, 1.25)):
-        best = {"aligned": 1e30, "odd": 1e30}
-        for rep in range(-1, 10):
-            for which in ("aligned", "odd"):
-                t = timed(fn, which, restore)
+        seen = []
+        for _ in range(3):  # (a timing assertion: up to three rounds of it)
+            best = {"aligned": 1e30, "odd": 1e30}
+            for rep in range(-1, 10):
+                for which in ("aligned", "odd"):
+                    t = timed(fn, which, restore)
+                    if rep >= 0:
+                        best[which] = min(best[which], t)
+            assert int(helper[0].item()) & 0xffffffff in (0, 0xffffffff)
+            seen.append(best)
+            if best["odd"] <= allowed * best["aligned"]:
+                break
+        else:
+            raise AssertionError((fn.__name__, seen))
+
+
+@pytest.mark.perf
+@pytest.mark.parametrize("ar", [F64, F32])
+def test_trsv_sweep_has_no_cliff_at_144_row_blocks(gpu, ar):
+    """The reference's sweep (`/root/reference/cuda/trsv_benchmark.cu:200-203`: n = 100,
+    200, ... inside a 24000-wide matrix, upper / unit) must not get slower towards a
+    LARGER size. Until round 4 it did at 144 row blocks: n = 18400 took 285 us and 18500
+    243 - the launcher's rule gave solves of up to 144 row blocks prefetching workgroups,
+    which under round 4's front loop cost 2-25 % (profiles/r05_trsv_prefetch_ab.txt).
+    Timed as the CLI does (minimum of 10 event-timed solves), the two sizes alternated;
+    a timing assertion, so up to three rounds of it: t(18400) <= 1.05 t(18560)."""
+    torch, accblas = gpu
+    lda = 24000
+    sizes = (18400, 18560)
+    A = uniform(torch, max(sizes) * lda, torch.float32, 91, scale=1.0 / lda ** 0.5)
+    x0 = uniform(torch, max(sizes), torch.float32, 92)
+    x = x0.clone()
+    helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+
+    def timed(n):
+        x.copy_(x0)
+        torch.cuda.synchronize()
+        a, b = accblas.Event(), accblas.Event()
+        a.record()
+        accblas.acc_trsv(ar, F32, accblas.UPPER, accblas.UNIT, n, A, lda, x, 1, helper)
+        b.record()
+        b.synchronize()
+        return a.elapsed_ms(b) * 1e3
+
+    seen = []
+    for _ in range(3):
+        best = {n: 1e30 for n in sizes}
+        for rep in range(-2, 10):
+            for n in sizes:
+                t = timed(n)
                 if rep >= 0:
-                    best[which] = min(best[which], t)
-        assert int(helper[0].item()) & 0xffffffff in (0, 0xffffffff)
-        assert best["odd"] <= allowed * best["aligned"], (fn.__name__, best)
+                    best[n] = min(best[n], t)
+        assert not accblas.trsv_status(helper)
+        seen.append(best)
+        if best[18400] <= 1.05 * best[18560]:
+            return
+    raise AssertionError(seen)

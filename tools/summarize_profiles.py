@@ -64,12 +64,12 @@ def main():
     }
     with open(os.path.join(PROF, f"{tag}_gemv_pmc.json"), "w") as f:
         json.dump(summary, f, indent=1)
-    with open(os.path.join(PROF, "traffic.json"), "w") as f:
-        # the counters belong to ONE version of the kernel: bench.py drops the
-        # figure when csrc/gemv_kernels.hpp has changed since
-        json.dump({"source": f"profiles/{tag}_gemv_pmc.json",
-                   "gemv_vec_bytes_per_launch": read_bytes + write_bytes,
-                   "gemv_kernels_sha256": kernel_source_hash()}, f, indent=1)
+    # the counters belong to ONE version of the kernel: profiles/traffic.json ties
+    # them to the SHA-256 of its sources, bench.py drops the figure when they changed
+    import subprocess
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "update_traffic.py"),
+                    f"gemv_32768_fp64_fp32=profiles/{tag}_gemv_pmc.json:"], check=True,
+                   stdout=subprocess.DEVNULL)
     # One kernel name can cover launches of different shapes (the headline GEMV
     # and the row block one GPU of eight would own run the same instantiation):
     # the trace grouped by kernel AND grid, so that every entry of the bench's

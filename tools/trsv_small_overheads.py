@@ -20,6 +20,28 @@ for name in names:
     lib.accblas_acc_trsv.argtypes = [ctypes.c_int] * 4 + [i64, vp, i64, vp, i64, vp, vp]
     libs.append(lib)
 helper = torch.zeros(2, dtype=torch.int32, device="cuda")
+# the floor under every number below: the same three measurements of a kernel
+# that does nothing but one 4-byte store
+word = torch.zeros(4, dtype=torch.int32, device="cuda")
+for _ in range(20):
+    word[:1].zero_()
+torch.cuda.synchronize()
+best = 1e9
+for _ in range(50):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    word[:1].zero_()
+    b.record()
+    b.synchronize()
+    best = min(best, a.elapsed_time(b) * 1e3)
+t0 = time.perf_counter()
+for _ in range(1000):
+    word[:1].zero_()
+host = (time.perf_counter() - t0) / 1000 * 1e6
+torch.cuda.synchronize()
+total = (time.perf_counter() - t0) / 1000 * 1e6
+print(f"floor (torch fill of one element): event {best:6.2f} us, host {host:5.2f} us/call, "
+      f"back-to-back {total:6.2f} us/launch", flush=True)
 for n in sizes:
     lda = 24000
     A = torch.rand(n * lda, dtype=torch.float32, device="cuda").mul_(2 / n ** 0.5).sub_(1 / n ** 0.5)

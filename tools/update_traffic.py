@@ -36,7 +36,15 @@ def main():
     for arg in sys.argv[1:]:
         entry, _, rest = arg.partition("=")
         pmc, _, needle = rest.partition(":")
-        cases = json.load(open(os.path.join(REPO, pmc)))["cases"]
+        summary = json.load(open(os.path.join(REPO, pmc)))
+        if "cases" not in summary:
+            # the headline's own summary (tools/summarize_profiles.py): one kernel
+            summary = {"cases": [{
+                "case": summary["kernel"],
+                "traffic_over_algorithmic": summary["traffic_over_algorithmic"],
+                "read_bytes_per_launch": summary["gemv_vec_bytes_per_launch"],
+                "write_bytes_per_launch": 0.0}]}
+        cases = summary["cases"]
         hits = [c for c in cases if needle in c["case"] and "traffic_over_algorithmic" in c]
         assert len(hits) == 1, (arg, [c["case"] for c in cases])
         case = hits[0]
