@@ -89,7 +89,7 @@ int trsv_small_option_value();
  *  by solve inside a 24000-wide matrix (profiles/r05_trsv_kernel_switch.txt):
  *  equal at 3200, the 128-row kernel 1-4 % faster at 3400 ... 3600 and 3-7 % at
  *  3800 ... 4000 (fp64 and fp32 arithmetic; 2-byte storage from 3000 on). 8-byte
- *  storage: nowhere any more. Until round
+ *  storage: from n = 61440 (`ACCBLAS_TRSV_WIDE_MIN_N_8BYTE`). Until round
  *  3 the 128-row kernel (two half-width steps in flight are all its registers
  *  allow) won below 17000 and beyond 32768; since round 4 the 64-row kernel's
  *  relay variant keeps its ring of panels in flight and its workgroups draw
@@ -101,6 +101,13 @@ int trsv_small_option_value();
  *  2785 | 2705 (within 3 % of each other from 52000 on). */
 #ifndef ACCBLAS_TRSV_WIDE_MIN_N
 #define ACCBLAS_TRSV_WIDE_MIN_N 3328
+#endif
+/** 8-byte storage: the 64-row relay kernel up to here (20-30 % ahead at 16384 ...
+ *  40000), the 128-row kernel with its split row blocks beyond - 2-3 % faster
+ *  from 61440 on in rounds 4 and 5 (profiles/r05_trsv_f64_storage_unfolded.txt:
+ *  65536 lower 2595 against 2666 us, upper 2616 against 2655). */
+#ifndef ACCBLAS_TRSV_WIDE_MIN_N_8BYTE
+#define ACCBLAS_TRSV_WIDE_MIN_N_8BYTE 61440
 #endif
 
 
@@ -153,7 +160,8 @@ int trsv_dispatch(bool upper, bool unit_diag, int64_t n, const MtxView &mtx,
     const bool use_wide =
         wide != 0 && dev::trsv_wide_applicable(upper, mtx, any_alignment) &&
         (wide == 2 ||
-         (n >= ACCBLAS_TRSV_WIDE_MIN_N && sizeof(st_type) < 8));
+         (sizeof(st_type) < 8 ? n >= ACCBLAS_TRSV_WIDE_MIN_N
+                              : n >= ACCBLAS_TRSV_WIDE_MIN_N_8BYTE));
     if (use_wide) {
         return check_hip(
             dev::launch_trsv_wide<ar_type>(upper, unit_diag, mtx, x, helper,

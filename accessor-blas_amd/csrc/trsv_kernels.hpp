@@ -1598,12 +1598,17 @@ constexpr unsigned trsv_single_block_pad()
  *  storage 512 18.2 | 17.6, 1024 27.2 | 29.2, 1500 35.4 | 44.2, 2048 44.5 |
  *  52.9, 8192 160 | 222, 16384 329 | 461; 4-byte storage 1024 26.3 | 24.7, 2048
  *  42.9 | 44.2, 3000 57.7 | 65.6, 4096 72.1 | 74.9 (from there the 128-row
- *  kernel takes over), 24000 431 | 475, 65536 1614 | 2208. */
+ *  kernel takes over), 24000 431 | 475, 65536 1614 | 2208. Round 5, finer steps
+ *  inside the reference's 24000-wide matrix (profiles/r05_trsv_relay_threshold.txt,
+ *  relay | direct): 4-byte storage 1024 25.4 | 24.8, 1280 29.7 | 30.5, 1536 33.5 |
+ *  35.4, 2000 42.4 | 45.8; 8-byte storage 896 24.8 | 24.5, 960 25.8 | 27.4, 1000
+ *  26.9 | 27.8 - the thresholds moved from 2048 / 1024 to 1152 / 960 (the sweep's
+ *  n = 2000 and n = 1000 were 4 % slower than the next size). */
 #ifndef ACCBLAS_TRSV_RELAY_MIN_N
-#define ACCBLAS_TRSV_RELAY_MIN_N 2048
+#define ACCBLAS_TRSV_RELAY_MIN_N 1152
 #endif
 #ifndef ACCBLAS_TRSV_RELAY_MIN_N_8BYTE
-#define ACCBLAS_TRSV_RELAY_MIN_N_8BYTE 1024
+#define ACCBLAS_TRSV_RELAY_MIN_N_8BYTE 960
 #endif
 constexpr index_type trsv_relay_min_n = ACCBLAS_TRSV_RELAY_MIN_N;
 

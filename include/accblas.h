@@ -87,13 +87,13 @@ size_t accblas_dtype_size(accblas_dtype t);
  *                 n >= 3328 use
  *                 128-row blocks (`kernel::trsv_wide`: half as many dependent
  *                 hops through memory, the folded panel held in registers),
- *                 everything else - 8-byte storage at every size - 64-row blocks
+ *                 everything else - 8-byte storage below n = 61440 - 64-row blocks
  *                 (`kernel::trsv`); 0 = 64-row blocks only; 2 = 128-row blocks
  *                 whenever the operands allow it.
  *   "trsv_relay"  64-row kernel only: 1 (default) = the far sweep's x goes
  *                 through a loader wave and LDS where that was measured to pay
- *                 (fp16 storage, fp32 arithmetic; fp64 arithmetic from n = 1024
- *                 with 8-byte and from n = 2048 with 4-byte storage);
+ *                 (fp16 storage, fp32 arithmetic; fp64 arithmetic from n = 960
+ *                 with 8-byte and from n = 1152 with 4-byte storage);
  *                 0 = never; 2 = always.
  *   "trsv_small"  1 (default) = systems of at most 128 unknowns are solved by
  *                 one workgroup without a workspace (`kernel::trsv_small`:

@@ -236,7 +236,8 @@ def test_trsv_split_row_blocks_match_oracle_and_unsplit_bits(gpu, ar, st, unit, 
     columns of the later blocks; here forced from block 100 on, so that n = 20008
     exercises both split shapes): against the semantic oracle, bit-for-bit
     repeatable, and with the SAME summation structure whatever the helpers'
-    timing (a second solve gives the same bits)."""
+    timing (a second solve gives the same bits) and whatever the launch's form
+    (a workgroup per ticket, or one per CU drawing tickets)."""
     torch, accblas = gpu
     # 157 row blocks: 100..124 in 5 parts (owners keep 48 columns), 125..146 in
     # 8 parts and 147..156 in 16 parts (owners keep 16; an owner takes the 15
@@ -262,13 +263,28 @@ def test_trsv_split_row_blocks_match_oracle_and_unsplit_bits(gpu, ar, st, unit, 
             torch.cuda.synchronize()
             assert int(helper[0].item()) & 0xffffffff == 0xffffffff
             runs.append(dx)
+        # the same solve by one workgroup per CU drawing the 561 tickets until
+        # none is left (option "trsv_wide_persistent": the row block as an
+        # out-of-line function inside a ticket loop), twice: the workspace must
+        # come back re-armed from a launch whose workgroups end with a final draw
+        accblas.set_option("trsv_wide_persistent", 1)
+        looped = []
+        for _ in range(2):
+            dx = torch.from_numpy(b).cuda()
+            accblas.acc_trsv(ar, st, uplo, accblas.UNIT if unit else accblas.NON_UNIT, n, dA, lda,
+                             dx, 1, helper)
+            torch.cuda.synchronize()
+            assert int(helper[0].item()) & 0xffffffff == 0xffffffff
+            looped.append(dx)
     finally:
         accblas.set_option("trsv_wide", 1)
         accblas.set_option("trsv_wide_split_from", 0)
+        accblas.set_option("trsv_wide_persistent", 0)
     err = oracle.rel_error(want.astype(np.float64), runs[0].cpu().numpy().astype(np.float64))
     tol = {F16: 1e-1, F32: 1e-5, F64: 1e-11}[st]
     assert err <= tol, err
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    assert torch.equal(runs[0], looped[0]) and torch.equal(runs[0], looped[1])
 
 
 @pytest.mark.parametrize("upper", [False, True])
