@@ -14,7 +14,7 @@ REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 SOURCES = {
     "gemv": ["gemv_kernels.hpp"],
     "dot": ["dot_kernels.hpp"],
-    "trsv": ["trsv_wide_kernels.hpp", "trsv_kernels.hpp"],
+    "trsv": ["trsv_wide_kernels.hpp", "trsv_wide_detail.hpp", "trsv_wide_launch.hpp", "trsv_kernels.hpp"],
 }
 
 
