@@ -9,37 +9,6 @@
 
 
 namespace {
-
-
-int validate_dot(const accblas_handle *handle, int64_t n, const void *x,
-                 int64_t incx, const void *y, int64_t incy, const void *res)
-{
-    if (handle == nullptr) {
-        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER,
-                                  "dot: handle is NULL");
-    }
-    if (n < 0) {
-        return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT, "dot: n < 0");
-    }
-    if (incx < 1 || incy < 1) {
-        return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
-                                  "dot: increments must be >= 1");
-    }
-    if (res == nullptr) {
-        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER, "dot: res is NULL");
-    }
-    if (n > 0 && (x == nullptr || y == nullptr)) {
-        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER,
-                                  "dot: x or y is NULL");
-    }
-    return ACCBLAS_OK;
-}
-
-
-}  // namespace
-
-
-namespace {
 /** status[1] <- status[0], status[0] <- 0, as one atomic exchange (the 16-byte
  *  status slot of a handle's workspace: word 0 = the sticky mark the dot
  *  kernels write, word 1 = what the last `accblas_dot_status` took). */
@@ -57,7 +26,7 @@ int accblas_dot(accblas_handle *handle, accblas_dtype vt, int64_t n,
                 const void *x, int64_t incx, const void *y, int64_t incy,
                 void *res, void *stream)
 {
-    const int status = validate_dot(handle, n, x, incx, y, incy, res);
+    const int status = accblas::validate_dot(handle, n, x, incx, y, incy, res);
     if (status != ACCBLAS_OK) {
         return status;
     }
@@ -84,7 +53,7 @@ int accblas_acc_dot(accblas_handle *handle, accblas_dtype ar, accblas_dtype st,
                     int64_t incx, const void *y, int64_t incy, void *res,
                     void *stream)
 {
-    const int status = validate_dot(handle, n, x, incx, y, incy, res);
+    const int status = accblas::validate_dot(handle, n, x, incx, y, incy, res);
     if (status != ACCBLAS_OK) {
         return status;
     }

@@ -7,40 +7,6 @@
 #include "gemv_kernels.hpp"
 
 
-namespace {
-
-
-int validate_gemv(int64_t rows, int64_t cols, const void *A, int64_t lda,
-                  const void *x, int64_t incx, const void *res, int64_t incres)
-{
-    if (rows < 0 || cols < 0) {
-        return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
-                                  "gemv: negative size");
-    }
-    if (lda < cols) {
-        // `gen_mtx` rejects the same condition (cuda/matrix_helper.cuh:31-33)
-        return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
-                                  "gemv: row stride smaller than cols");
-    }
-    if (incx < 1 || incres < 1) {
-        return accblas::set_error(ACCBLAS_ERR_INVALID_ARGUMENT,
-                                  "gemv: increments must be >= 1");
-    }
-    if (rows > 0 && res == nullptr) {
-        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER,
-                                  "gemv: res is NULL");
-    }
-    if (rows > 0 && cols > 0 && (A == nullptr || x == nullptr)) {
-        return accblas::set_error(ACCBLAS_ERR_NULL_POINTER,
-                                  "gemv: A or x is NULL");
-    }
-    return ACCBLAS_OK;
-}
-
-
-}  // namespace
-
-
 namespace accblas {
 inline dev::gemv_skew_mode gemv_skew_option()
 {
@@ -55,7 +21,7 @@ int accblas_gemv(accblas_dtype vt, int64_t rows, int64_t cols, double alpha,
                  const void *A, int64_t lda, const void *x, int64_t incx,
                  double beta, void *res, int64_t incres, void *stream)
 {
-    const int status = validate_gemv(rows, cols, A, lda, x, incx, res, incres);
+    const int status = accblas::validate_gemv(rows, cols, A, lda, x, incx, res, incres);
     if (status != ACCBLAS_OK) {
         return status;
     }
@@ -83,7 +49,7 @@ int accblas_acc_gemv(accblas_dtype ar, accblas_dtype st, int64_t rows,
                      const void *x, int64_t incx, double beta, void *res,
                      int64_t incres, void *stream)
 {
-    const int status = validate_gemv(rows, cols, A, lda, x, incx, res, incres);
+    const int status = accblas::validate_gemv(rows, cols, A, lda, x, incx, res, incres);
     if (status != ACCBLAS_OK) {
         return status;
     }

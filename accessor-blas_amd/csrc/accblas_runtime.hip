@@ -73,6 +73,10 @@ size_t accblas_dtype_size(accblas_dtype t)
         return 4;
     case ACCBLAS_F64:
         return 8;
+    case ACCBLAS_I16:
+        return 2;
+    case ACCBLAS_I32:
+        return 4;
     }
     return 0;
 }

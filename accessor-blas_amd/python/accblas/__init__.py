@@ -20,12 +20,13 @@ PACKAGE_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))
 LIB_PATH = os.path.join(PACKAGE_ROOT, "lib", "libaccblas_hip.so")
 
 F16, F32, F64 = 0, 1, 2
+I16, I32 = 3, 4  # integer storage: the scaled_* entry points only
 UPPER, LOWER = 0, 1
 NON_UNIT, UNIT = 0, 1
 DOT_DETERMINISTIC, DOT_ATOMIC = 0, 1
 
-DTYPE_NAMES = {F16: "f16", F32: "f32", F64: "f64"}
-DTYPE_BYTES = {F16: 2, F32: 4, F64: 8}
+DTYPE_NAMES = {F16: "f16", F32: "f32", F64: "f64", I16: "i16", I32: "i32"}
+DTYPE_BYTES = {F16: 2, F32: 4, F64: 8, I16: 2, I32: 4}
 
 
 class AccblasError(RuntimeError):
@@ -82,6 +83,10 @@ SIGNATURES = {
     "accblas_acc_dot": (_int, [_vp, _int, _int, _int, _i64, _vp, _i64, _vp, _i64, _vp,
                                _vp]),
     "accblas_dot_status": (_int, [_vp, _vp, ctypes.POINTER(_int)]),
+    "accblas_scaled_acc_gemv": (_int, [_int, _int, _int, _i64, _i64, _dbl, _vp, _i64, _vp,
+                                       _vp, _i64, _dbl, _vp, _i64, _vp]),
+    "accblas_scaled_acc_dot": (_int, [_vp, _int, _int, _int, _i64, _vp, _i64, _vp, _vp,
+                                      _i64, _vp, _vp]),
     "accblas_trsv": (_int, [_int, _int, _int, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "accblas_acc_trsv": (_int, [_int, _int, _int, _int, _i64, _vp, _i64, _vp, _i64,
                                 _vp, _vp]),
@@ -155,7 +160,8 @@ def dtype_of(tensor):
 
 def torch_dtype(dt):
     import torch
-    return {F16: torch.float16, F32: torch.float32, F64: torch.float64}[dt]
+    return {F16: torch.float16, F32: torch.float32, F64: torch.float64, I16: torch.int16,
+            I32: torch.int32}[dt]
 
 
 def _stream(stream):
@@ -269,6 +275,23 @@ def dot(handle, vt, n, x, incx, y, incy, res, stream=None):
     """`dot<ValueType>` (`cuda/dot_kernels.cuh:192-206`); res = device scalar."""
     _check(load().accblas_dot(handle.raw, vt, n, _ptr(x), incx, _ptr(y), incy, _ptr(res),
                               _stream(stream)))
+
+
+def scaled_acc_gemv(ar, a_st, v_st, rows, cols, alpha, A, lda, scalars, x, incx, beta, res,
+                    incres, stream=None):
+    """GEMV whose matrix is a `range<scaled_reduced_row_major<2, ar, a_st, 0b10>>`
+    (value = storage x scalars[column]); x and res reduced_row_major<2, ar, v_st>."""
+    _check(load().accblas_scaled_acc_gemv(ar, a_st, v_st, rows, cols, alpha, _ptr(A), lda,
+                                          _ptr(scalars), _ptr(x), incx, beta, _ptr(res),
+                                          incres, _stream(stream)))
+
+
+def scaled_acc_dot(handle, ar, x_st, y_st, n, x, incx, x_scalar, y, incy, res, stream=None):
+    """dot of a scaled vector (an (n, 1) `scaled_reduced_row_major` range with its one
+    scalar) with a reduced_row_major vector; `res` = a device scalar of type `ar`."""
+    _check(load().accblas_scaled_acc_dot(handle.raw, ar, x_st, y_st, n, _ptr(x), incx,
+                                         _ptr(x_scalar), _ptr(y), incy, _ptr(res),
+                                         _stream(stream)))
 
 
 def acc_dot(handle, ar, st, res_t, n, x, incx, y, incy, res, stream=None):

@@ -40,7 +40,11 @@ extern "C" {
 typedef enum accblas_dtype {
     ACCBLAS_F16 = 0,
     ACCBLAS_F32 = 1,
-    ACCBLAS_F64 = 2
+    ACCBLAS_F64 = 2,
+    /* integer STORAGE types: accepted by the accblas_scaled_* entry points
+     * only, every other call returns ACCBLAS_ERR_UNSUPPORTED_TYPES for them */
+    ACCBLAS_I16 = 3,
+    ACCBLAS_I32 = 4
 } accblas_dtype;
 
 /* Mirrors `enum class tmtx_t { upper, lower }` (cuda/trsv_kernels.cuh:22). */
@@ -228,6 +232,33 @@ int accblas_acc_dot(accblas_handle *handle, accblas_dtype ar, accblas_dtype st,
  * atomics cannot stall, cuda/dot_kernels.cuh:158-160); ACCBLAS_DOT_ATOMIC mode
  * never waits. */
 int accblas_dot_status(accblas_handle *handle, void *stream, int *expired);
+
+/* ---- other accessor kinds: scaled_reduced_row_major --------------------
+ * The reference's README lists the accessor family its kernels accept ("all
+ * others work accordingly", README.md:19); its launchers only build
+ * reduced_row_major (cuda/gemv_kernels.cuh:178-189, dot_kernels.cuh:233-243).
+ * These two build `range<scaled_reduced_row_major<2, ar, st, 0b10>>` - value =
+ * (ar)storage x scalar, one arithmetic-type scalar per COLUMN index - for the
+ * matrix of a GEMV / the first vector of a dot, and reduced_row_major for the
+ * operands beside it. Scaled storage: I16, I32, F16 or F32; the other
+ * operands: F32 or F64 storage; arithmetic F32 or F64 (anything else:
+ * ACCBLAS_ERR_UNSUPPORTED_TYPES).
+ *   gemv: res = alpha * A x + beta * res, A(i, j) = (ar)A[i * lda + j] *
+ *         scalars[j]; `scalars` = cols device values of the arithmetic type.
+ *   dot:  *res = sum_i ((ar)x[i * incx] * x_scalar[0]) * y[i * incy]; x is an
+ *         (n, 1) range, its one column has ONE scalar (a device value of the
+ *         arithmetic type); `res` = a device scalar of the arithmetic type. */
+int accblas_scaled_acc_gemv(accblas_dtype ar, accblas_dtype a_st,
+                            accblas_dtype v_st, int64_t rows, int64_t cols,
+                            double alpha, const void *A, int64_t lda,
+                            const void *scalars, const void *x, int64_t incx,
+                            double beta, void *res, int64_t incres,
+                            void *stream);
+int accblas_scaled_acc_dot(accblas_handle *handle, accblas_dtype ar,
+                           accblas_dtype x_st, accblas_dtype y_st, int64_t n,
+                           const void *x, int64_t incx, const void *x_scalar,
+                           const void *y, int64_t incy, void *res,
+                           void *stream);
 
 /* ---- TRSV: x <- T^{-1} x in place ----------------------------------------
  * T = upper/lower triangle of the row-major n x n matrix A (row stride lda),

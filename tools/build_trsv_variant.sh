@@ -17,6 +17,6 @@ for src in accblas_trsv accblas_trsv_f32 accblas_trsv_f64; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-for src in accblas_runtime accblas_gemv accblas_dot; do cp "$root/build/$src.o" "$out/$src.o"; done
+for src in accblas_runtime accblas_gemv accblas_dot accblas_scaled; do cp "$root/build/$src.o" "$out/$src.o"; done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 "$out"/*.o -o "$root/lib_$name/libaccblas_hip.so"
 echo "built $root/lib_$name/libaccblas_hip.so with: $flags"

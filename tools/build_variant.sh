@@ -11,7 +11,7 @@ out=$root/build_x/$name
 mkdir -p "$out" "$root/lib_$name"
 common="-std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=fast -I$root/include -I$root/csrc -Wall -Wno-unused-function -Wno-pass-failed $flags"
 pids=()
-for src in accblas_runtime accblas_gemv accblas_dot accblas_trsv accblas_trsv_f32 accblas_trsv_f64; do
+for src in accblas_runtime accblas_gemv accblas_dot accblas_trsv accblas_trsv_f32 accblas_trsv_f64 accblas_scaled; do
   /opt/rocm/bin/hipcc $common -c "$root/csrc/$src.hip" -o "$out/$src.o" &
   pids+=($!)
 done

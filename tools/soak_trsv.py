@@ -37,6 +37,9 @@ def main(iterations=4000, seed=7, max_n=14000):
         family = int(rng.integers(0, 4))
         accblas.set_option("trsv_wide", (1, 0, 2, 2)[family])
         accblas.set_option("trsv_wide_split_from", 98 if family == 3 else 0)
+        # (solves with more tickets than CUs: a workgroup per ticket, or one per
+        # CU drawing tickets - the two forms share a workspace and an epoch)
+        accblas.set_option("trsv_wide_persistent", int(rng.integers(0, 2)))
         # every third solve on a view that is not 16-byte aligned: a base a few
         # elements into the allocation and an odd row stride
         off, lda = (int(rng.integers(1, 8)), max_n - 1 - 2 * int(rng.integers(0, 3))) if it % 3 == 2 else (0, max_n)
@@ -66,6 +69,7 @@ def main(iterations=4000, seed=7, max_n=14000):
     torch.cuda.synchronize()
     accblas.set_option("trsv_wide", 1)
     accblas.set_option("trsv_wide_split_from", 0)
+    accblas.set_option("trsv_wide_persistent", 0)
     print(f"soak passed: {iterations} solves, worst checked residual {worst:.2e}")
 
 
