@@ -114,7 +114,9 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < splits.size(); ++i) {
             CHECK(hipMemcpy(x, x0, n * sizeof(st_type), hipMemcpyDeviceToDevice));
             CHECK(hipEventRecord(start, nullptr));
-            CHECK(launch_trsv_wide_split<ar_type>(false, true, m, xv, helper, session, nullptr, splits[i]));
+            // (the CU count as the library passes it: row blocks below it fold at once)
+            CHECK(launch_trsv_wide_split<ar_type>(false, true, m, xv, helper, session, nullptr, splits[i],
+                                                  prop.multiProcessorCount));
             CHECK(hipEventRecord(stop, nullptr));
             CHECK(hipEventSynchronize(stop));
             float ms;
