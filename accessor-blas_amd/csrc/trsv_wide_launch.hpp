@@ -48,7 +48,7 @@ constexpr int trsv_wide_tail_blocks = 32;      // tail: at least this many block
 constexpr int trsv_wide_max_tail_blocks = 96;  // ... at most this many
 constexpr int trsv_wide_last_parts = 16;       // last third of the tail
 constexpr int trsv_wide_tail_deferred = 16;    // columns a tail owner keeps
-constexpr int trsv_wide_whole_blocks = 64;     // blocks beyond the CUs kept whole
+constexpr int trsv_wide_whole_blocks = 32;     // blocks beyond the CUs kept whole, at most
 
 /** How a solve of n unknowns is split on a device with `num_cus` CUs: row
  *  blocks that cannot be resident from the start (more blocks than CUs) get
@@ -79,13 +79,18 @@ inline trsv_wide_split trsv_wide_split_for(index_type n, int num_cus,
     // The first blocks beyond the CU count stay whole: the owner of a split
     // block starts when the front is still far away (a CU frees up per hop AND
     // per finished helper) and then holds its CU idle, a whole block that
-    // starts early sweeps its own columns meanwhile. Up to 64 of them, half of
-    // what there is (profiles/r02_trsv_split_first.txt: first split block
-    // 256 -> 320 at n = 49152 / 57344 / 65536: 965 -> 922, 1190 -> 1128,
-    // 1447 -> 1414 us; n = 40000, 313 blocks: 288 as good as 256, none worse)
-    int whole = blocks > num_cus ? (blocks - num_cus) / 2 : 0;
-    whole = whole < trsv_wide_whole_blocks ? whole
-                                                   : trsv_wide_whole_blocks;
+    // starts early sweeps its own columns meanwhile. How many: round 2 kept half
+    // of what there is, up to 64 (profiles/r02_trsv_split_first.txt: first
+    // split block 256 -> 320 at n = 49152 / 57344 / 65536: 965 -> 922, 1190 ->
+    // 1128, 1447 -> 1414 us). Re-measured in round 5 with the front loop and
+    // without deferred folds for resident blocks (tools/tune_trsv_split.hip,
+    // all candidates alternated in one process, profiles/r05_trsv_split_first.txt):
+    // a sixth of what there is, up to 32 - first split block 288 instead of 320
+    // at n = 57344: 1143 -> 1078 us, 272 at 49152: 907 -> 866, 272 at 45056:
+    // 774 -> 735, 264 at 40000: 670 -> 656; 65536 is flat from 272 to 320
+    // (1360-1366), 36000 from 258 to 274.
+    int whole = blocks > num_cus ? (blocks - num_cus) / 6 : 0;
+    whole = whole < trsv_wide_whole_blocks ? whole : trsv_wide_whole_blocks;
     // (`split_from` > 0: the caller's choice of the first split block)
     const int wanted = split_from > 0 ? split_from : num_cus + whole;
     const int first = wanted > min_first ? wanted : min_first;
