@@ -14,6 +14,10 @@
 //   sK+inv   the same behind s_dcache_inv
 //   s1>vec   scalar poll of the block's last line, then ONE vector load of
 //            the block (what a two-stage hand-over would cost)
+//   s8w      ALL eight waves poll two lines each (both loads issued, one wait)
+//            and meet through an LDS counter: the whole block through scalar
+//            registers, as a kernel would have to do it (do the scalar cache's
+//            misses overlap?); v8w = the same with 16-lane vector loads
 // Memory kinds for the granules: ordinary hipMalloc and uncached
 // (hipDeviceMallocUncached), because a scalar load has no sc1 bit: whether it
 // sees a remote XCD's write-through store is part of the question.
@@ -40,7 +44,7 @@ typedef float vec4 __attribute__((ext_vector_type(4)));
 typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
 typedef unsigned uvec16 __attribute__((ext_vector_type(16)));
 
-enum path { VEC = 0, VEC_PRIO = 1, S1 = 2, S4 = 3, S1_INV = 4, S1_THEN_VEC = 5, S2 = 6 };
+enum path { VEC = 0, VEC_PRIO = 1, S1 = 2, S4 = 3, S1_INV = 4, S1_THEN_VEC = 5, S2 = 6, S8W = 7, V8W = 8 };
 
 __device__ __forceinline__ int xcc_id()
 {
@@ -94,6 +98,7 @@ __global__ __launch_bounds__(512) void chain(unsigned *g, int hops, unsigned *st
     const int xcc = xcc_id();
     if (threadIdx.x == 0) {
         lds[0] = 0;
+        lds[2] = 0;
         lds[1] = atomicAdd(&state[xcc], 1u);
     }
     __syncthreads();
@@ -119,6 +124,84 @@ __global__ __launch_bounds__(512) void chain(unsigned *g, int hops, unsigned *st
             }
         }
         if (acc == 12345.678f) *sink = acc;
+        return;
+    }
+    if (Path == S8W || Path == V8W) {
+        // every wave waits for its two lines of each block this participant
+        // consumes, then counts itself in; wave 0 publishes when all eight have
+        unsigned long long t0 = 0;
+        bool failed = false;
+        if (wave == 0 && lane == 0) state[32 + me] = xcc;
+        for (int h = me; h < hops && !failed; h += 2) {
+            if (h > 0) {
+                const unsigned long long mine_bits =
+                    (unsigned long long)(g + (size_t)(h - 1) * 256 + wave * 32);
+                const unsigned *mine = (const unsigned *)(
+                    ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mine_bits >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)mine_bits));
+                const unsigned serial = (unsigned)h;
+                unsigned spins = 0;
+                while (true) {
+                    bool seen;
+                    if (Path == S8W) {
+                        uvec16 a, b;
+                        asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\t"
+                                     "s_load_dwordx16 %1, %2, 0x40 glc\n\t"
+                                     "s_waitcnt lgkmcnt(0)"
+                                     : "=&s"(a), "=&s"(b) : "s"(mine) : "memory");
+                        seen = line_has(a, serial) && line_has(b, serial);
+                    } else {
+                        unsigned long long v = 0;
+                        const unsigned *p = mine + (lane & 15) * 2;
+                        asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
+                                     : "=v"(v) : "v"(p) : "memory");
+                        seen = __all((unsigned)(v >> 32) == serial);
+                    }
+                    if (seen) break;
+                    if (++spins > (1u << 18)) {
+                        failed = true;
+                        break;
+                    }
+                }
+                if (lane == 0) atomicAdd(&lds[2], 1u);  // LDS
+                if (wave != 0) continue;
+                // wave 0: all eight waves of this hop counted in (8 per consumed hop)
+                const unsigned want = 8u * (unsigned)((h - me) / 2 + (me == 0 ? 0 : 1));
+                unsigned polls = 0;
+                while (*(volatile unsigned *)&lds[2] < want && ++polls < (1u << 22)) {
+                }
+            } else {
+                if (wave != 0) continue;
+                t0 = realtime();
+            }
+            if (wave == 0) {
+                uvec4 out;
+                out[0] = (unsigned)lane;
+                out[1] = (unsigned)h + 1;
+                out[2] = (unsigned)lane + 64;
+                out[3] = (unsigned)h + 1;
+                unsigned *dst = g + (size_t)h * 256 + lane * 4;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(out) : "memory");
+            }
+        }
+        if (wave == 0) {
+            if (failed && lane == 0) state[16] = 1;
+            if (me == (hops - 1) % 2 || failed) {
+                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+                if (lane == 0) {
+                    unsigned one = 1;
+                    unsigned *dp = state + 17;
+                    asm volatile("global_store_dword %0, %1, off sc1" : : "v"(dp), "v"(one) : "memory");
+                }
+            }
+            if (me == 0) {
+                const unsigned long long t1 = realtime();
+                if (lane == 0) {
+                    state[34] = (unsigned)(t1 - t0);
+                    state[35] = (unsigned)((t1 - t0) >> 32);
+                }
+            }
+        }
         return;
     }
     if (wave != 0) {
@@ -253,6 +336,8 @@ int main(int argc, char **argv)
     CHECK(hipFuncSetAttribute((const void *)chain<S4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     CHECK(hipFuncSetAttribute((const void *)chain<S1_INV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     CHECK(hipFuncSetAttribute((const void *)chain<S1_THEN_VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CHECK(hipFuncSetAttribute((const void *)chain<S8W>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CHECK(hipFuncSetAttribute((const void *)chain<V8W>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     for (int mode = 0; mode < 4; ++mode) {
         // idle / the two CUs' other waves stream / the whole chip streams /
         // the chip streams but the two CUs do not (the solve's tail: the
@@ -269,6 +354,10 @@ int main(int argc, char **argv)
             RUN(S2, "s2");
             RUN(S4, "s4");
             RUN(S1_THEN_VEC, "s1>vec");
+            if (!own) {
+                RUN(S8W, "s8w");
+                RUN(V8W, "v8w");
+            }
 #undef RUN
         }
     }
