@@ -180,6 +180,9 @@ def _launch_once(world, argv, command, deadline, timeout, poll):
             env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
                        WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            # (this pool's host driver supports dmabuf IPC only: without it RCCL
+            # fails with hipIpcGetMemHandle: invalid argument)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             out = tempfile.TemporaryFile(mode="w+")
             outputs.append(out)
             children.append(subprocess.Popen(
@@ -676,6 +679,8 @@ def main():
         # no launcher: become the parent of one child per GPU (before torch,
         # accblas or anything else that could touch the GPU is imported)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.gpus > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (as in launch_ranks)
     import numpy as np
     import torch
 
