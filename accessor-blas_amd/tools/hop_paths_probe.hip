@@ -9,6 +9,8 @@
 // Poll paths compared:
 //   vec      global_load_dwordx4 sc1 of the whole block (the library's poll)
 //   vec+prio the same with s_setprio 3 on the polling wave
+//   vec ld-nt / st-nt / nt-nt: the non-temporal hint on the poll, the
+//            publishing store, or both
 //   sK       s_load_dwordx16 glc of K 64-byte lines of the block (scalar data
 //            cache path: does not queue in the CU's vector memory pipeline)
 //   sK+inv   the same behind s_dcache_inv
@@ -44,7 +46,7 @@ typedef float vec4 __attribute__((ext_vector_type(4)));
 typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
 typedef unsigned uvec16 __attribute__((ext_vector_type(16)));
 
-enum path { VEC = 0, VEC_PRIO = 1, S1 = 2, S4 = 3, S1_INV = 4, S1_THEN_VEC = 5, S2 = 6, S8W = 7, V8W = 8 };
+enum path { VEC = 0, VEC_PRIO = 1, S1 = 2, S4 = 3, S1_INV = 4, S1_THEN_VEC = 5, S2 = 6, S8W = 7, V8W = 8, VEC_NT = 9, VEC_STNT = 10, VEC_NTNT = 11 };
 
 __device__ __forceinline__ int xcc_id()
 {
@@ -76,12 +78,17 @@ __device__ __forceinline__ bool line_has(const uvec16 v, unsigned serial)
            v[9] == serial && v[11] == serial && v[13] == serial && v[15] == serial;
 }
 
-__device__ __forceinline__ uvec4 vector_block(const unsigned *block, int lane)
+__device__ __forceinline__ uvec4 vector_block(const unsigned *block, int lane, bool nt = false)
 {
     uvec4 v;
     const unsigned *p = block + lane * 4;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=v"(v) : "v"(p) : "memory");
+    if (nt) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1 nt\n\ts_waitcnt vmcnt(0)"
+                     : "=v"(v) : "v"(p) : "memory");
+    } else {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=v"(v) : "v"(p) : "memory");
+    }
     return v;
 }
 
@@ -233,8 +240,9 @@ __global__ __launch_bounds__(512) void chain(unsigned *g, int hops, unsigned *st
             unsigned spins = 0;
             while (true) {
                 bool seen;
-                if (Path == VEC || Path == VEC_PRIO) {
-                    const uvec4 v = vector_block(block, lane);
+                if (Path == VEC || Path == VEC_PRIO || Path == VEC_NT || Path == VEC_STNT ||
+                    Path == VEC_NTNT) {
+                    const uvec4 v = vector_block(block, lane, Path == VEC_NT || Path == VEC_NTNT);
                     seen = __all(v[1] == serial && v[3] == serial);
                 } else if (Path == S1 || Path == S1_INV || Path == S1_THEN_VEC) {
                     if (Path == S1_INV) asm volatile("s_dcache_inv" : : : "memory");
@@ -268,7 +276,11 @@ __global__ __launch_bounds__(512) void chain(unsigned *g, int hops, unsigned *st
         out[2] = (unsigned)lane + 64;
         out[3] = (unsigned)h + 1;
         unsigned *dst = g + (size_t)h * 256 + lane * 4;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(out) : "memory");
+        if (Path == VEC_STNT || Path == VEC_NTNT) {
+            asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(dst), "v"(out) : "memory");
+        } else {
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(out) : "memory");
+        }
     }
     if (failed && lane == 0) state[16] = 1;
     if (acc != 0 && lane == 0) atomicAdd(&state[18], 1u);
@@ -336,6 +348,9 @@ int main(int argc, char **argv)
     CHECK(hipFuncSetAttribute((const void *)chain<S4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     CHECK(hipFuncSetAttribute((const void *)chain<S1_INV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     CHECK(hipFuncSetAttribute((const void *)chain<S1_THEN_VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CHECK(hipFuncSetAttribute((const void *)chain<VEC_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CHECK(hipFuncSetAttribute((const void *)chain<VEC_STNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CHECK(hipFuncSetAttribute((const void *)chain<VEC_NTNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     CHECK(hipFuncSetAttribute((const void *)chain<S8W>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     CHECK(hipFuncSetAttribute((const void *)chain<V8W>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     for (int mode = 0; mode < 4; ++mode) {
@@ -349,6 +364,9 @@ int main(int argc, char **argv)
 #define RUN(P, text) run<P>(text, g, kn, hops, own, chip, state, buf, count, sink)
             RUN(VEC, "vec");
             RUN(VEC_PRIO, "vec+prio");
+            RUN(VEC_NT, "vec ld-nt");
+            RUN(VEC_STNT, "vec st-nt");
+            RUN(VEC_NTNT, "vec nt-nt");
             RUN(S1, "s1");
             RUN(S1_INV, "s1+inv");
             RUN(S2, "s2");
